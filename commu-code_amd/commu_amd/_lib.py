@@ -1,0 +1,99 @@
+"""ctypes binding of libcommu_hip.so (the C ABI declared in include/commu_hip.h).
+
+This is the stub a maintainer of the reference would add to call the MI355X kernels from
+Python; it is also the only way the product package reaches the GPU.  There is NO fallback:
+if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcommu_hip.so")
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_f = C.c_float
+c_z = C.c_size_t
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("rd", c_p), ("r_w_bias", c_p), ("r_r_bias", c_p),
+                ("reset", c_p), ("ld_qkv", c_i), ("ld_rd", c_i), ("ld_o", c_i), ("T", c_i), ("M", c_i),
+                ("B", c_i), ("H", c_i), ("DH", c_i), ("same_length", c_i), ("sshift", c_i), ("scale", c_f)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [("o", c_p), ("dout", c_p), ("lse", c_p), ("delta", c_p), ("kt", c_p), ("rdt", c_p),
+                ("qut", c_p), ("dot", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("qv_out", c_p),
+                ("dsk", c_p), ("du_part", c_p), ("dvb_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
+                ("Jpad", c_i), ("Tpad", c_i), ("Wr", c_i)]
+
+
+# name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
+PROTOTYPES = {
+    "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
+    "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
+    "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_p],
+    "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
+    "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p],
+    "commu_layernorm_bwd_nblocks": [c_i],
+    "commu_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
+    "commu_colsum_bf16": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "commu_colsum_f32": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "commu_ce_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p],
+    "commu_ce_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "commu_masked_mean": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+    "commu_loss_grad": [c_p, c_i, c_i, c_p, c_f, c_p, c_p],
+    "commu_grad_norm": [c_p, c_z, c_p, c_i, c_p, c_p],
+    "commu_adam_step": [c_p, c_p, c_p, c_p, c_p, c_z, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_p],
+    "commu_cast_f32_bf16": [c_p, c_p, c_z, c_p],
+    "commu_cast_bf16_f32": [c_p, c_p, c_z, c_p],
+    "commu_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
+    "commu_transpose_f32_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
+    "commu_copy_bf16": [c_p, c_p, c_z, c_p],
+    "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_i, c_p, c_p, c_p],
+    "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
+    "commu_attn_rdt_shift": [c_i],
+    "commu_attn_delta": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
+    "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "commu_hip_version": [],
+}
+_RESTYPE = {"commu_hip_version": C.c_char_p}
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_attn_rdt_shift", "commu_hip_version"}
+
+_lib = None
+
+
+class CommuHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CommuHipError(
+            f"{LIB_PATH} not found: build it with `python commu-code_amd/build.py` "
+            "(the product path has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_i)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an entry point and raise on a non-zero status."""
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if name not in _NOCHECK and rc != 0:
+        raise CommuHipError(f"{name} failed with status {rc}")
+    return rc

@@ -1,0 +1,303 @@
+"""Tensor-level wrappers over the C ABI (include/commu_hip.h).
+
+PyTorch is used here only for device memory and the current HIP stream; all arithmetic is done
+by the kernels in libcommu_hip.so.  Every wrapper refuses CPU tensors: there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnBwdDesc, AttnDesc, CommuHipError, call
+
+EPI_BIAS, EPI_RELU, EPI_RESID, EPI_RELUMASK, EPI_OUT_F32 = 1, 2, 4, 8, 16
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+# use LDS transpose reads in the dW GEMM (mode 1) unless told otherwise
+TN_MODE = 1
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CommuHipError("commu_amd kernels need GPU tensors (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rowmajor2d(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D tensor with unit column stride, got {tuple(t.shape)} / {t.stride()}")
+    return t.stride(0)
+
+
+def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None, out_f32=False):
+    """out[M,N] = A[M,K] @ B[N,K]^T (+bias)(+resid)(relu)(relu-mask).  A, B bf16."""
+    lda, ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K and A.dtype == BF16 and B.dtype == BF16
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=F32 if out_f32 else BF16)
+    ldc = _rowmajor2d(out, "out")
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+        assert bias.dtype == F32 and bias.numel() >= N
+    if resid is not None:
+        flags |= EPI_RESID
+        assert resid.dtype == BF16
+    if relu:
+        flags |= EPI_RELU
+    if relu_mask is not None:
+        flags |= EPI_RELUMASK
+        assert relu_mask.dtype == BF16
+    if out.dtype == F32:
+        flags |= EPI_OUT_F32
+    call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid),
+         0 if resid is None else _rowmajor2d(resid, "resid"), _p(relu_mask),
+         0 if relu_mask is None else _rowmajor2d(relu_mask, "relu_mask"), flags, _s())
+    return out
+
+
+def tn_slices(M: int, N: int, K: int) -> int:
+    """Number of m-slices so that the grid has >= ~512 workgroups."""
+    tiles = ((N + 127) // 128) * ((K + 63) // 64 if K <= 64 else (K + 127) // 128)
+    s = max(1, min(64, (512 + tiles - 1) // tiles))
+    return max(1, min(s, (M + 255) // 256))
+
+
+def gemm_tn(A, B, out, *, accumulate=False, slabs=None, mode=None):
+    """out[N,K] (+)= A[M,N]^T @ B[M,K]  (fp32 out; bf16 inputs).  Split over M into slabs that
+    are summed by commu_reduce_slabs_f32.  `out` may be a strided 2-D view only if contiguous."""
+    lda, ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
+    M, N = A.shape
+    K = B.shape[1]
+    assert B.shape[0] == M and out.shape == (N, K) and out.dtype == F32 and out.is_contiguous()
+    ns = tn_slices(M, N, K)
+    if slabs is None or slabs.numel() < ns * N * K:
+        slabs = torch.empty(ns * N * K, device=A.device, dtype=F32)
+    call("commu_gemm_tn_bf16", _p(A), lda, _p(B), ldb, _p(slabs), K, N * K, M, N, K, ns,
+         TN_MODE if mode is None else mode, _s())
+    call("commu_reduce_slabs_f32", _p(out), _p(slabs), N * K, ns, N * K, 1 if accumulate else 0, _s())
+    return out
+
+
+def embed_fwd(tok, E, out=None):
+    ntok = tok.numel()
+    D = E.shape[1]
+    assert tok.dtype == torch.int64 and E.dtype == F32 and E.is_contiguous() and tok.is_contiguous()
+    if out is None:
+        out = torch.empty(ntok, D, device=E.device, dtype=BF16)
+    call("commu_embed_fwd", _p(tok), _p(E), _p(out), out.stride(0), ntok, D, math.sqrt(D), _s())
+    return out
+
+
+def embed_bwd(tok, dX, dE, accumulate=True):
+    V, D = dE.shape
+    call("commu_embed_bwd", _p(tok), _p(dX), dX.stride(0), _p(dE), tok.numel(), D, V, math.sqrt(D),
+         1 if accumulate else 0, _s())
+    return dE
+
+
+def posemb(inv_freq, K, D, out=None):
+    if out is None:
+        out = torch.empty(K, D, device=inv_freq.device, dtype=BF16)
+    call("commu_posemb_fwd", _p(inv_freq), _p(out), out.stride(0), K, D, _s())
+    return out
+
+
+def layernorm_fwd(z, gamma, beta, y=None, mean=None, rstd=None, eps=1e-5):
+    rows, D = z.shape
+    y = torch.empty_like(z) if y is None else y
+    mean = torch.empty(rows, device=z.device, dtype=F32) if mean is None else mean
+    rstd = torch.empty(rows, device=z.device, dtype=F32) if rstd is None else rstd
+    call("commu_layernorm_fwd", _p(z), z.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), _p(mean), _p(rstd),
+         rows, D, eps, _s())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None):
+    """Returns (dz, part) with part [nblk, 3, D]: partial column sums of dy*xhat, dy, dz."""
+    rows, D = z.shape
+    nblk = call("commu_layernorm_bwd_nblocks", rows)
+    dz = torch.empty_like(z) if dz is None else dz
+    if part is None:
+        part = torch.empty(nblk, 3, D, device=z.device, dtype=F32)
+    call("commu_layernorm_bwd", _p(dy), dy.stride(0), _p(z), z.stride(0), _p(mean), _p(rstd), _p(gamma), _p(dz),
+         dz.stride(0), _p(part), rows, D, _s())
+    return dz, part[:nblk]
+
+
+def colsum(X, out):
+    """out[c] += sum_r X[r, c]  (X bf16 or fp32)."""
+    rows, cols = X.shape
+    name = "commu_colsum_bf16" if X.dtype == BF16 else "commu_colsum_f32"
+    call(name, _p(X), X.stride(0), rows, cols, _p(out), _s())
+    return out
+
+
+def ce_fwd(logits, target, V):
+    rows = logits.shape[0]
+    nll = torch.empty(rows, device=logits.device, dtype=F32)
+    lse = torch.empty(rows, device=logits.device, dtype=F32)
+    call("commu_ce_fwd", _p(logits), logits.stride(0), _p(target), _p(nll), _p(lse), rows, V, _s())
+    return nll, lse
+
+
+def ce_bwd(logits, target, lse, g, V, dlogits=None):
+    rows = logits.shape[0]
+    if dlogits is None:
+        dlogits = torch.empty(rows, logits.stride(0), device=logits.device, dtype=BF16)
+    call("commu_ce_bwd", _p(logits), logits.stride(0), _p(target), _p(lse), _p(g), _p(dlogits), dlogits.stride(0),
+         rows, V, _s())
+    return dlogits
+
+
+def masked_mean(nll, target, pad, scale, ws_sum, ws_cnt, out):
+    call("commu_masked_mean", _p(nll), _p(target), nll.numel(), pad, scale, _p(ws_sum), _p(ws_cnt), _p(out), _s())
+    return out
+
+
+def loss_grad(target, pad, ws_cnt, scale, g):
+    call("commu_loss_grad", _p(target), target.numel(), pad, _p(ws_cnt), scale, _p(g), _s())
+    return g
+
+
+def grad_norm(g, part, out):
+    call("commu_grad_norm", _p(g), g.numel(), _p(part), part.numel(), _p(out), _s())
+    return out
+
+
+def adam_step(p, g, m, v, p_bf16, lr, step, gnorm=None, clip=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    call("commu_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, step,
+         _p(gnorm), clip, _s())
+
+
+def cast_bf16(x, out=None):
+    out = torch.empty(x.shape, device=x.device, dtype=BF16) if out is None else out
+    call("commu_cast_f32_bf16", _p(x), _p(out), x.numel(), _s())
+    return out
+
+
+def cast_f32(x, out=None):
+    out = torch.empty(x.shape, device=x.device, dtype=F32) if out is None else out
+    call("commu_cast_bf16_f32", _p(x), _p(out), x.numel(), _s())
+    return out
+
+
+def transpose_to_bf16(x, out=None):
+    """out[c, r] = bf16(x[r, c]) for a 2-D fp32 or bf16 x."""
+    rows, cols = x.shape
+    out = torch.empty(cols, rows, device=x.device, dtype=BF16) if out is None else out
+    name = "commu_transpose_f32_bf16" if x.dtype == F32 else "commu_transpose_bf16"
+    call(name, _p(x), x.stride(0), _p(out), out.stride(0), rows, cols, _s())
+    return out
+
+
+def transpose_heads(src, J, B, H, DH, W, off=0, bias=None, out=None):
+    """out[b,h,f, off+j] = src[(j*B+b), h*DH+f] (+bias[h*DH+f]); other columns zero.  src is a 2-D view."""
+    if out is None:
+        out = torch.empty(B, H, DH, W, device=src.device, dtype=BF16)
+    call("commu_transpose_heads", _p(src), src.stride(0), _p(bias), _p(out), J, B, H, DH, W, off, _s())
+    return out
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem_len):
+    d = AttnDesc()
+    d.q, d.k, d.v, d.rd = q.data_ptr(), k.data_ptr(), v.data_ptr(), rd.data_ptr()
+    d.r_w_bias, d.r_r_bias = u.data_ptr(), vb.data_ptr()
+    d.reset = reset.data_ptr() if reset is not None else None
+    d.ld_qkv, d.ld_rd, d.ld_o = q.stride(0), rd.stride(0), ld_o
+    d.T, d.M, d.B, d.H, d.DH = T, M, B, H, DH
+    K = T + M
+    # model.py:549-568: mask_len = klen - mem_len; shift = qlen - mask_len if mask_len > 0 else qlen
+    d.same_length = 1 if same_length else 0
+    mask_len = K - mem_len
+    d.sshift = (T - mask_len) if mask_len > 0 else T
+    d.scale = 1.0 / math.sqrt(DH)
+    return d
+
+
+class AttnWorkspace:
+    """Buffers of one attention call (sizes depend on T, M, B, H, DH only)."""
+
+    def __init__(self, T, M, B, H, DH, device):
+        K = T + M
+        self.T, self.M, self.B, self.H, self.DH, self.K = T, M, B, H, DH, K
+        self.Jpad = round_up(K, 64)
+        self.Tpad = round_up(T, 64)
+        self.Wr = round_up(128 + 8 + K + 192, 8)
+        self.QT = (T + 63) // 64
+        self.device = device
+
+
+def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None, vt=None):
+    """q: 2-D view [T*B, H*DH] (row stride ld_qkv), k, v: [(T+M)*B, H*DH]; rd: [K, H*DH] by distance.
+    Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], vt)."""
+    K = T + M
+    Jpad = round_up(K, 64)
+    if vt is None:
+        vt = torch.empty(B, H, DH, Jpad, device=q.device, dtype=BF16)
+    transpose_heads(v, K, B, H, DH, Jpad, 0, None, vt)
+    if out is None:
+        out = torch.empty(T * B, H * DH, device=q.device, dtype=BF16)
+    if lse is None:
+        lse = torch.empty(B, H, T, device=q.device, dtype=F32)
+    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len)
+    call("commu_relattn_fwd", C.byref(d), _p(vt), Jpad, _p(out), _p(lse), _s())
+    return out, lse, vt
+
+
+def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, dq, dk, dv,
+                drd, du, dvb):
+    """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
+    drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
+    dev = q.device
+    K = T + M
+    Jpad, Tpad = round_up(K, 64), round_up(T, 64)
+    Wr = round_up(128 + 8 + K + 192, 8)
+    QT = (T + 63) // 64
+    sft = call("commu_attn_rdt_shift", M)
+    delta = torch.empty(B, H, T, device=dev, dtype=F32)
+    call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
+    kt = transpose_heads(k, K, B, H, DH, Jpad)
+    qut = transpose_heads(q, T, B, H, DH, Tpad, 0, u)
+    dot = transpose_heads(dout, T, B, H, DH, Tpad)
+    rdt = transpose_heads(rd, K, 1, H, DH, Wr, 128 + sft)
+    qv_out = torch.empty(T * B, H * DH, device=dev, dtype=BF16)
+    ld_dsk = round_up(K, 8)
+    dsk = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
+    du_part = torch.empty(B * QT, H * DH, device=dev, dtype=F32)
+    dvb_part = torch.empty(B * QT, H * DH, device=dev, dtype=F32)
+    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len)
+    e = AttnBwdDesc()
+    e.o, e.dout, e.lse, e.delta = o.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    e.kt, e.rdt, e.qut, e.dot = kt.data_ptr(), rdt.data_ptr(), qut.data_ptr(), dot.data_ptr()
+    e.dq, e.dk, e.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    e.qv_out, e.dsk = qv_out.data_ptr(), dsk.data_ptr()
+    e.du_part, e.dvb_part = du_part.data_ptr(), dvb_part.data_ptr()
+    e.ld_dqkv, e.ld_dsk, e.Jpad, e.Tpad, e.Wr = dq.stride(0), ld_dsk, Jpad, Tpad, Wr
+    assert dk.stride(0) == dq.stride(0) and dv.stride(0) == dq.stride(0)
+    call("commu_relattn_bwd", C.byref(d), C.byref(e), _s())
+    colsum(du_part, du)
+    colsum(dvb_part, dvb)
+    # dRd[d, h*DH+f] = sum_m dSk[h][m][d] * (q+v)[m][h*DH+f]
+    tmp = torch.empty(ld_dsk, DH, device=dev, dtype=F32)      # pad columns of dsk are zero
+    for h in range(H):
+        gemm_tn(dsk[h], qv_out[:, h * DH:(h + 1) * DH], tmp)
+        drd[:, h * DH:(h + 1) * DH].copy_(tmp[:K])
+    return delta

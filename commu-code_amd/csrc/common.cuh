@@ -1,0 +1,66 @@
+// Shared device helpers for the ComMU Transformer-XL hot-path kernels (gfx950 / CDNA4 only).
+// wave = 64 lanes; MFMA fragments follow the 16x16x32 bf16 layout:
+//   A operand: lane l holds A[row = l&15][k = 8*(l>>4) .. +8]
+//   B operand: lane l holds B[k = 8*(l>>4) .. +8][col = l&15]
+//   C/D      : lane l holds C[row = 4*(l>>4) + reg][col = l&15], reg = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+#define WAVE 64
+#define LDS_AS __attribute__((address_space(3)))
+
+#define COMMU_LAUNCH_CHECK()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce across the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give each XCD a contiguous
+// range of logical tile ids so neighbouring tiles share an L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *(const bf16x8*)p; }
+__device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *(bf16x8*)p = v; }

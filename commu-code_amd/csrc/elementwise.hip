@@ -1,0 +1,577 @@
+// HBM-bound kernels of the Transformer-XL hot path (gfx950): embedding gather/scatter,
+// sinusoid table, LayerNorm fwd/bwd, column sums (bias grads), log-softmax + NLL fwd/bwd,
+// grad-norm + clipped Adam, bf16 shadow cast / transpose, XL-memory window copy.
+// One wave (64 lanes) per row wherever a row reduction is needed; 16-byte accesses.
+#include "common.cuh"
+#include "commu_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// K1: x[m,:] = E[tok[m],:] * sqrt(D)       (commu/model/model.py:409-420)
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
+                                 bf16* __restrict__ out, int ldo, int ntok, int D, float scale) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= ntok) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = E + (size_t)tok[m] * D;
+    bf16* dst = out + (size_t)m * ldo;
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 v = *(const f32x4*)(src + c);
+        bf16x4 o = {f2bf(v[0] * scale), f2bf(v[1] * scale), f2bf(v[2] * scale), f2bf(v[3] * scale)};
+        *(bf16x4*)(dst + c) = o;
+    }
+}
+
+// dE[v,:] (+)= scale * sum_{m: tok[m]==v} dX[m,:]   -- one workgroup per vocabulary row, no
+// atomics, deterministic (V = 729 rows only; the token list is L2 resident).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(
+    const int64_t* __restrict__ tok, const bf16* __restrict__ dX, int ldx, float* __restrict__ dE,
+    int ntok, int D, float scale, int accumulate) {
+    __shared__ int hits[1024];
+    __shared__ int nhit;
+    const int v = blockIdx.x, tid = threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};      // column tid + 256*k, D <= 1024
+    for (int base = 0; base < ntok; base += 1024) {
+        if (tid == 0) nhit = 0;
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) {
+            const int m = base + i;
+            if (m < ntok && tok[m] == v) hits[atomicAdd(&nhit, 1)] = m;
+        }
+        __syncthreads();
+        const int n = nhit;
+        for (int h = 0; h < n; ++h) {
+            const bf16* row = dX + (size_t)hits[h] * ldx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tid + 256 * k;
+                if (c < D) acc[k] += bf2f(row[c]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tid + 256 * k;
+        if (c < D) {
+            float* p = dE + (size_t)v * D + c;
+            *p = (accumulate ? *p : 0.f) + acc[k] * scale;
+        }
+    }
+}
+
+// K2: sinusoid table indexed by DISTANCE d (pos = d): out[d] = [sin(d f) | cos(d f)]
+// (commu/model/model.py:142-147; the reference's row k of pos_emb is distance klen-1-k).
+__global__ void posemb_kernel(const float* __restrict__ inv_freq, bf16* __restrict__ out, int ld,
+                              int K, int D) {
+    const int half = D >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= K * half) return;
+    const int d = idx / half, i = idx - d * half;
+    const float ang = (float)d * inv_freq[i];
+    out[(size_t)d * ld + i] = f2bf(sinf(ang));
+    out[(size_t)d * ld + half + i] = f2bf(cosf(ang));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over D (eps inside sqrt, biased variance; torch.nn.LayerNorm, model.py:171,214,352,179)
+constexpr int LN_MAXC = 2;   // D <= 1024: lane owns 8-element chunks at column 8*lane + 512*c
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(
+    const bf16* __restrict__ z, int ldz, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16* __restrict__ y, int ldy, float* __restrict__ mean,
+    float* __restrict__ rstd, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float x[LN_MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int col = lane * 8 + 512 * c;
+        if (col < D) {
+            bf16x8 v = ld_bf16x8(z + (size_t)row * ldz + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[c][e] = bf2f(v[e]); s += x[c][e]; }
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int col = lane * 8 + 512 * c;
+        if (col < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = x[c][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int col = lane * 8 + 512 * c;
+        if (col < D) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = f2bf((x[c][e] - mu) * rs * gamma[col + e] + beta[col + e]);
+            st_bf16x8(y + (size_t)row * ldy + col, o);
+        }
+    }
+}
+
+// dz = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  partial column sums of
+// dy*xhat (dgamma), dy (dbeta) and dz (bias grad of the Linear feeding the LN) per block.
+constexpr int LNB_ROWS = 64;   // rows per block (16 per wave)
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ z, int ldz,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    bf16* __restrict__ dz, int lddz, float* __restrict__ part, int rows, int D) {
+    __shared__ float red[4][3][1024];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float ag[LN_MAXC][8], ab[LN_MAXC][8], az[LN_MAXC][8], gm[LN_MAXC][8];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ag[c][e] = ab[c][e] = az[c][e] = 0.f;
+            const int col = lane * 8 + 512 * c + e;
+            gm[c][e] = (col < D) ? gamma[col] : 0.f;
+        }
+    const int r0 = blockIdx.x * LNB_ROWS + w * 16;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int row = r0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAXC][8], gy[LN_MAXC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int col = lane * 8 + 512 * c;
+            if (col < D) {
+                bf16x8 vz = ld_bf16x8(z + (size_t)row * ldz + col);
+                bf16x8 vd = ld_bf16x8(dy + (size_t)row * lddy + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = bf2f(vd[e]);
+                    xh[c][e] = (bf2f(vz[e]) - mu) * rs;
+                    gy[c][e] = d * gm[c][e];
+                    s1 += gy[c][e];
+                    s2 += gy[c][e] * xh[c][e];
+                    ag[c][e] += d * xh[c][e];
+                    ab[c][e] += d;
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int col = lane * 8 + 512 * c;
+            if (col < D) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = rs * (gy[c][e] - m1 - xh[c][e] * m2);
+                    o[e] = f2bf(v);
+                    az[c][e] += bf2f(o[e]);
+                }
+                st_bf16x8(dz + (size_t)row * lddz + col, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int col = lane * 8 + 512 * c + e;
+            if (col < D) { red[w][0][col] = ag[c][e]; red[w][1][col] = ab[c][e]; red[w][2][col] = az[c][e]; }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
+        const int k = i / D, col = i - k * D;
+        part[((size_t)blockIdx.x * 3 + k) * D + col] =
+            red[0][k][col] + red[1][k][col] + red[2][k][col] + red[3][k][col];
+    }
+}
+
+// out[c] += sum_r X[r, c]   (atomics: one per block per column; out pre-zeroed or a grad to add into)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, int rows,
+                                                     int cols, float* __restrict__ out,
+                                                     int rows_per_block) {
+    __shared__ float red[4][256];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 256 + lane * 4;
+    const int rbeg = blockIdx.y * rows_per_block;
+    const int rend = min(rows, rbeg + rows_per_block);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {
+        for (int r = rbeg + w; r < rend; r += 4) {
+            const T* p = X + (size_t)r * ldx + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < cols) a[e] += (float)p[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + c, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10: nll[m] = logsumexp(logits[m, :V]) - logits[m, target[m]]   (model.py:64-73)
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int ldl,
+                                                     const int64_t* __restrict__ target,
+                                                     float* __restrict__ nll, float* __restrict__ lse,
+                                                     int rows, int V) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = logits + (size_t)row * ldl;
+    float mx = -3.0e38f;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += expf(p[c] - mx);
+    s = wave_sum(s);
+    const float l = mx + logf(s);
+    if (lane == 0) {
+        lse[row] = l;
+        nll[row] = l - p[target[row]];
+    }
+}
+
+// dlogits[m, n] = g[m] * (softmax(logits[m])[n] - [n == target[m]]), bf16, zero in pad columns
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ldl,
+                                                     const int64_t* __restrict__ target,
+                                                     const float* __restrict__ lse,
+                                                     const float* __restrict__ g,
+                                                     bf16* __restrict__ dlogits, int ldd, int rows,
+                                                     int V) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = logits + (size_t)row * ldl;
+    bf16* o = dlogits + (size_t)row * ldd;
+    const float l = lse[row], gr = g[row];
+    const int t = (int)target[row];
+    for (int c = lane; c < ldd; c += 64) {
+        float v = 0.f;
+        if (c < V) v = gr * (expf(p[c] - l) - (c == t ? 1.f : 0.f));
+        o[c] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K12/K13: global grad norm (deterministic two-stage) and clipped Adam on the flat buffers
+// (train.py:159-169; torch.optim.Adam defaults; clip_grad_norm_ coefficient = min(1, c/(n+1e-6)))
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n,
+                                                            float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            f32x4 v = *(const f32x4*)(g + i);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        } else {
+            for (size_t j = i; j < n; ++j) s += g[j] * g[j];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = sqrtf(s);     // out[0] = total L2 norm
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16* __restrict__ pb, size_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2,
+                                                   const float* __restrict__ gnorm, float clip) {
+    float coef = 1.f;
+    if (gnorm != nullptr && clip > 0.f) coef = fminf(1.f, clip / (gnorm[0] + 1e-6f));
+    const float step = lr / bc1, isb2 = 1.f / sqrtf(bc2);
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+        for (int e = 0; e < cnt; ++e) {
+            const float gr = g[i + e] * coef;
+            const float mm = b1 * m[i + e] + (1.f - b1) * gr;
+            const float vv = b2 * v[i + e] + (1.f - b2) * gr * gr;
+            m[i + e] = mm;
+            v[i + e] = vv;
+            const float np = p[i + e] - step * mm / (sqrtf(vv) * isb2 + eps);
+            p[i + e] = np;
+            if (pb) pb[i + e] = f2bf(np);
+        }
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = f2bf(in[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = bf2f(in[i]);
+}
+
+// out[c, r] = in[r, c]  (bf16 weight shadows W^T for the dX GEMMs); 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ in, int ldi,
+                                                             bf16* __restrict__ out, int ldo, int rows,
+                                                             int cols) {
+    __shared__ bf16 t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        t[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(size_t)(r0 + r) * ldi + c0 + c] : f2bf(0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < cols && r0 + r < rows) out[(size_t)(c0 + c) * ldo + r0 + r] = t[r][c];
+    }
+}
+
+// same with an fp32 source (master weights -> transposed bf16 shadow in one pass)
+__global__ __launch_bounds__(256) void transpose_f32_bf16_kernel(const float* __restrict__ in, int ldi,
+                                                                 bf16* __restrict__ out, int ldo,
+                                                                 int rows, int cols) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        t[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(size_t)(r0 + r) * ldi + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < cols && r0 + r < rows) out[(size_t)(c0 + c) * ldo + r0 + r] = f2bf(t[r][c]);
+    }
+}
+
+// g[m] = (target[m] != pad) ? scale / count : 0      (autograd of the masked mean, train.py:148-149)
+__global__ void loss_grad_kernel(const int64_t* __restrict__ target, int n, int pad,
+                                 const int* __restrict__ cnt, float scale, float* __restrict__ g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] = (target[i] != pad) ? scale / (float)max(cnt[0], 1) : 0.f;
+}
+
+// sum of nll over non-pad targets (+ count): the forward of the masked mean
+__global__ __launch_bounds__(256) void masked_sum_kernel(const float* __restrict__ nll,
+                                                         const int64_t* __restrict__ target, int n,
+                                                         int pad, float* __restrict__ sum,
+                                                         int* __restrict__ cnt) {
+    float s = 0.f;
+    int c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (target[i] != pad) { s += nll[i]; ++c; }
+    s = wave_sum(s);
+    c = (int)wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(sum, s); if (c) atomicAdd(cnt, c); }
+}
+__global__ void masked_mean_final_kernel(const float* sum, const int* cnt, float scale, float* out) {
+    out[0] = scale * sum[0] / (float)max(cnt[0], 1);
+}
+
+__global__ void copy_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x)
+        ((bf16x8*)dst)[i] = ((const bf16x8*)src)[i];
+}
+
+}  // namespace
+
+static inline unsigned cap_blocks(size_t want) {
+    return (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+}
+
+extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, int ldo, int ntok, int D,
+                               float scale, hipStream_t stream) {
+    if (ntok <= 0) return 0;
+    if (D % 4) return -22;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, stream, tok, E, (bf16*)out,
+                       ldo, ntok, D, scale);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, float* dE, int ntok, int D,
+                               int V, float scale, int accumulate, hipStream_t stream) {
+    if (D > 1024) return -22;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, stream, tok, (const bf16*)dX, ldx, dE,
+                       ntok, D, scale, accumulate);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K, int D, hipStream_t stream) {
+    const int n = K * (D / 2);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_freq, (bf16*)out,
+                       ld, K, D);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, const float* beta, void* y,
+                                   int ldy, float* mean, float* rstd, int rows, int D, float eps,
+                                   hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (D > 1024 || (D % 8) || (ldz % 8) || (ldy % 8)) return -22;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)z,
+                       ldz, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, D, eps);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_layernorm_bwd_nblocks(int rows) { return (rows + LNB_ROWS - 1) / LNB_ROWS; }
+
+extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const float* mean,
+                                   const float* rstd, const float* gamma, void* dz, int lddz,
+                                   float* part, int rows, int D, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    if (D > 1024 || (D % 8)) return -22;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
+                       (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz,
+                       part, rows, D);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    int ny = (rows + 255) / 256;
+    if (ny > 256) ny = 256;
+    const int rpb = (rows + ny - 1) / ny;
+    hipLaunchKernelGGL(colsum_kernel<bf16>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream,
+                       (const bf16*)X, ldx, rows, cols, out, rpb);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    int ny = (rows + 63) / 64;
+    if (ny > 256) ny = 256;
+    const int rpb = (rows + ny - 1) / ny;
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream, X, ldx,
+                       rows, cols, out, rpb);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse,
+                            int rows, int V, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, nll,
+                       lse, rows, V);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_ce_bwd(const float* logits, int ldl, const int64_t* target, const float* lse,
+                            const float* g, void* dlogits, int ldd, int rows, int V, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, lse,
+                       g, (bf16*)dlogits, ldd, rows, V);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out,
+                               hipStream_t stream) {
+    if (npart <= 0 || npart > 1024) return -22;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(npart), dim3(256), 0, stream, g, n, part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, part, npart, out);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n,
+                               float lr, float beta1, float beta2, float eps, int step,
+                               const float* gnorm, float clip, hipStream_t stream) {
+    if (n == 0) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
+                       (bf16*)p_bf16, n, lr, beta1, beta2, eps, bc1, bc2, gnorm, clip);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, in,
+                       (bf16*)out, n);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16*)in, out, n);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, int cols,
+                                    hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream,
+                       (const bf16*)in, ldi, (bf16*)out, ldo, rows, cols);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
+                                        hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
+                       stream, in, ldi, (bf16*)out, ldo, rows, cols);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_masked_mean(const float* nll, const int64_t* target, int n, int pad, float scale,
+                                 float* sum_ws, int* cnt_ws, float* out, hipStream_t stream) {
+    // out[0] = scale * mean(nll[target != pad]); cnt_ws keeps the count for commu_loss_grad
+    hipMemsetAsync(sum_ws, 0, sizeof(float), stream);
+    hipMemsetAsync(cnt_ws, 0, sizeof(int), stream);
+    if (n > 0)
+        hipLaunchKernelGGL(masked_sum_kernel, dim3(cap_blocks((n + 1023) / 1024)), dim3(256), 0, stream, nll,
+                           target, n, pad, sum_ws, cnt_ws);
+    hipLaunchKernelGGL(masked_mean_final_kernel, dim3(1), dim3(1), 0, stream, sum_ws, cnt_ws, scale, out);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_loss_grad(const int64_t* target, int n, int pad, const int* cnt_ws, float scale,
+                               float* g, hipStream_t stream) {
+    // g[m] = scale * (target[m] != pad) / cnt_ws[0]   (cnt_ws filled by commu_masked_mean)
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, target, n, pad, cnt_ws,
+                       scale, g);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_copy_bf16(const void* src, void* dst, size_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (n % 8) return -22;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(cap_blocks((n / 8 + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16*)src, (bf16*)dst, n / 8);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,363 @@
+// bf16 MFMA GEMMs for the Transformer-XL hot path (gfx950).
+//
+//  gemm_nt : C[M,N] = A[M,K] . B[N,K]^T (+ fused epilogue)       -- every forward Linear
+//            (reference: nn.Linear calls at commu/model/model.py:205,212,278,164,167,46) and
+//            every dX = dY . W backward (W passed pre-transposed, so it is NT again).
+//  gemm_tn : C[N,K] = sum_m A[m,N]^T . B[m,K]   (split over m)     -- every dW = dY^T . X.
+//
+// Tiling: 128x128 output tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA
+// 16x16x32 blocks, K step 32, register-staged double-buffered LDS (one barrier per K step).
+// The MFMA is issued "swapped" (weight rows as the A operand) so that each lane ends up with
+// 4 consecutive output columns of one row: 8-byte bf16x4 / 16-byte f32x4 stores.
+#include "common.cuh"
+#include "commu_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+// 64-byte LDS rows (32 bf16): XOR the 16-byte chunk index so that each ds_read_b128 lane
+// group ({0-3,12-15,20-27}, ...) touches 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int swz64(int row) { return ((row >> 3) & 1) * 3; }
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(
+    const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+    void* __restrict__ Cv, int ldc, int M, int N, int K,
+    const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr,
+    const bf16* __restrict__ rmask, int ldm, int flags, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, r16 = lane & 15, g = lane >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lrow = tid >> 2, lch = tid & 3;
+    const bf16* ap[2];
+    const bf16* bp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lrow + 64 * i;
+        ap[i] = A + (size_t)min(m0 + r, M - 1) * lda + lch * 8;
+        bp[i] = B + (size_t)min(n0 + r, N - 1) * ldb + lch * 8;
+    }
+    bf16x8 ra[2], rb[2];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = ld_bf16x8(ap[i] + kt * BK);
+            rb[i] = ld_bf16x8(bp[i] + kt * BK);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lrow + 64 * i;
+            const int off = r * BK + ((lch ^ swz64(r)) << 3);
+            st_bf16x8(&sA[buf][off], ra[i]);
+            st_bf16x8(&sB[buf][off], rb[i]);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int choff = (g ^ swz64(r16)) << 3;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = ld_bf16x8(&sA[buf][(wr * 64 + 16 * i + r16) * BK + choff]);
+            bfr[i] = ld_bf16x8(&sB[buf][(wc * 64 + 16 * i + r16) * BK + choff]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(bfr[ni], af[mi], acc[ni][mi]);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m = .. + r16][n = .. + 4g + reg]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr * 64 + 16 * mi + r16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc * 64 + 16 * ni + 4 * g;
+            if (n >= N) continue;
+            f32x4 v = acc[ni][mi];
+            const bool full = (n + 3 < N);
+            if (flags & COMMU_EPI_BIAS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) v[e] += bias[n + e];
+            }
+            if (flags & COMMU_EPI_RESID) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) v[e] += bf2f(resid[(size_t)m * ldr + n + e]);
+            }
+            if (flags & COMMU_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (flags & COMMU_EPI_RELUMASK) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N && !(bf2f(rmask[(size_t)m * ldm + n + e]) > 0.f)) v[e] = 0.f;
+            }
+            if (OUT_F32) {
+                float* C = (float*)Cv + (size_t)m * ldc + n;
+                if (full) {
+                    *(f32x4*)C = v;
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) C[e] = v[e];
+                }
+            } else {
+                bf16* C = (bf16*)Cv + (size_t)m * ldc + n;
+                if (full) {
+                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *(bf16x4*)C = o;
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < N) C[e] = f2bf(v[e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN: out[n, k] (fp32 slab per m-slice) = sum_{m in slice} A[m, n] * B[m, k].
+// Both operands have the contraction index m as their ROW index, so MFMA fragments (8
+// consecutive m per lane) are columns of the staged [32 m][128] LDS images.
+//   mode 1: ds_read_b64_tr_b16 transpose reads (2 per fragment)
+//   mode 0: ds_read_u16 gathers (8 per fragment) -- slow, correct by construction.
+constexpr int TM = 32;
+
+// swizzle of the 32-byte unit index (8 units per 256-byte row... 128 cols) used by the TN images
+__device__ __forceinline__ int swz_tn(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int NCOLS_B, int MODE>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(
+    const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
+    float* __restrict__ C, int ldc, size_t slab_stride, int Mtot, int N, int Kc, int m_per_slice) {
+    // image A: [32][128] bf16, image B: [32][NCOLS_B]; double buffered
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][TM * 128];
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][TM * NCOLS_B];
+    constexpr int WN = 64;                 // wave tile: 64 (n) x NCOLS_B/2 (k)
+    constexpr int WK = NCOLS_B / 2;
+    constexpr int KB = WK / 16;            // k blocks per wave (4 or 2)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 1, wc = w & 1, r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * NCOLS_B;
+    const int slice = blockIdx.z;
+    const int mbeg = slice * m_per_slice;
+    const int mend = min(Mtot, mbeg + m_per_slice);
+    const int nsteps = (mend - mbeg + TM - 1) / TM;
+
+    const int lrow = tid >> 4, lch = tid & 15;            // 16 rows x 16 chunks(16B) per pass
+    constexpr int CHB = NCOLS_B / 8;                      // 16-byte chunks per B row
+    const int browB = tid / CHB, bchB = tid % CHB;
+    constexpr int ROWS_PER_PASS_B = 256 / CHB;            // 16 (128 cols) or 32 (64 cols)
+    bf16x8 ra[2], rb[2];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto gload = [&](int st) {
+        const int mb = mbeg + st * TM;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mb + lrow + 16 * i;
+            const int n = n0 + lch * 8;
+            ra[i] = (m < mend && n < N) ? ld_bf16x8(A + (size_t)m * lda + n) : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < TM / ROWS_PER_PASS_B; ++i) {
+            const int m = mb + browB + ROWS_PER_PASS_B * i;
+            const int k = k0 + bchB * 8;
+            rb[i] = (m < mend && k < Kc) ? ld_bf16x8(B + (size_t)m * ldb + k) : zero8;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lrow + 16 * i;
+            const int ch = (((lch >> 1) ^ swz_tn(r)) << 1) | (lch & 1);
+            st_bf16x8(&sA[buf][r * 128 + ch * 8], ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM / ROWS_PER_PASS_B; ++i) {
+            const int r = browB + ROWS_PER_PASS_B * i;
+            int ch;
+            if (NCOLS_B == 128) ch = (((bchB >> 1) ^ swz_tn(r)) << 1) | (bchB & 1);
+            else ch = (((bchB >> 1) ^ (swz_tn(r) & 3)) << 1) | (bchB & 1);
+            st_bf16x8(&sB[buf][r * NCOLS_B + ch * 8], rb[i]);
+        }
+    };
+    // fragment = 8 consecutive m (8g .. 8g+7) of column `col` of an image with `ncols` columns
+    auto frag = [&](const bf16* img, int ncols, int colbase) -> bf16x8 {
+        bf16x8 f;
+        if (MODE == 1) {
+            // lane i of a 16-lane group supplies &img[8g + (i>>2) (+4)][colbase + 4*(i&3)]
+            const int i = r16;
+            const int c = colbase + 4 * (i & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 8 * g + (i >> 2) + 4 * h;
+                const int sw = (ncols == 128) ? swz_tn(r) : (swz_tn(r) & 3);
+                const int unit = (c >> 4) ^ sw;
+                const bf16* p = img + r * ncols + unit * 16 + (c & 15);
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p));
+                bf16x4 vb = __builtin_bit_cast(bf16x4, v);
+                f[4 * h + 0] = vb[0]; f[4 * h + 1] = vb[1]; f[4 * h + 2] = vb[2]; f[4 * h + 3] = vb[3];
+            }
+        } else {
+            const int c = colbase + r16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * g + e;
+                const int sw = (ncols == 128) ? swz_tn(r) : (swz_tn(r) & 3);
+                const int unit = (c >> 4) ^ sw;
+                f[e] = img[r * ncols + unit * 16 + (c & 15)];
+            }
+        }
+        return f;
+    };
+
+    f32x4 acc[KB][4];
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nsteps > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) gload(st + 1);
+        bf16x8 af[4], bfr[KB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag(sA[buf], 128, wr * WN + 16 * i);
+#pragma unroll
+        for (int i = 0; i < KB; ++i) bfr[i] = frag(sB[buf], NCOLS_B, wc * WK + 16 * i);
+        // swapped issue: D[k][n] -> lane holds out[n = .. + r16][k = .. + 4g + reg]
+#pragma unroll
+        for (int ki = 0; ki < KB; ++ki)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = mfma16(bfr[ki], af[ni], acc[ki][ni]);
+        if (st + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* Cs = C + (size_t)slice * slab_stride;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wr * WN + 16 * ni + r16;
+        if (n >= N) continue;
+#pragma unroll
+        for (int ki = 0; ki < KB; ++ki) {
+            const int k = k0 + wc * WK + 16 * ki + 4 * g;
+            if (k + 3 < Kc) {
+                *(f32x4*)(Cs + (size_t)n * ldc + k) = acc[ki][ni];
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < Kc) Cs[(size_t)n * ldc + k + e] = acc[ki][ni][e];
+            }
+        }
+    }
+}
+
+// dst[i] (+)= sum_s src[s*stride + i]
+__global__ void reduce_slabs_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n,
+                                    int nslabs, size_t stride, int accumulate) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t step = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += step) {
+        if (i + 3 < n) {
+            f32x4 s = *(const f32x4*)(src + i);
+            for (int k = 1; k < nslabs; ++k) s += *(const f32x4*)(src + (size_t)k * stride + i);
+            if (accumulate) s += *(const f32x4*)(dst + i);
+            *(f32x4*)(dst + i) = s;
+        } else {
+            for (size_t j = i; j < n; ++j) {
+                float s = src[j];
+                for (int k = 1; k < nslabs; ++k) s += src[(size_t)k * stride + j];
+                if (accumulate) s += dst[j];
+                dst[j] = s;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                  int M, int N, int K, const float* bias, const void* resid, int ldr,
+                                  const void* relu_mask, int ldm, int flags, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K % BK) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n);
+    if (flags & COMMU_EPI_OUT_F32)
+        hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
+                           (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
+                           (const bf16*)relu_mask, ldm, flags, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
+                           (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
+                           (const bf16*)relu_mask, ldm, flags, tiles_n);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs,
+                                  int ldc, size_t slab_stride, int M, int N, int K, int nslices,
+                                  int mode, hipStream_t stream) {
+    if (N <= 0 || K <= 0 || nslices <= 0) return 0;
+    if ((lda % 8) || (ldb % 8) || (ldc % 4) || (N % 8) || (K % 8)) return -22;
+    int mps = (M + nslices - 1) / nslices;
+    mps = ((mps + TM - 1) / TM) * TM;
+    const bool narrow = (K <= 64);
+    dim3 grid((N + 127) / 128, narrow ? (K + 63) / 64 : (K + 127) / 128, nslices);
+#define TN_LAUNCH(NC, MD)                                                                          \
+    hipLaunchKernelGGL((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,  \
+                       (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps)
+    if (narrow) {
+        if (mode) TN_LAUNCH(64, 1); else TN_LAUNCH(64, 0);
+    } else {
+        if (mode) TN_LAUNCH(128, 1); else TN_LAUNCH(128, 0);
+    }
+#undef TN_LAUNCH
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs,
+                                      size_t stride, int accumulate, hipStream_t stream) {
+    if (n == 0) return 0;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n,
+                       nslabs, stride, accumulate);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,145 @@
+/* commu_hip.h -- C ABI of libcommu_hip.so: MI355X (gfx950) kernels for ComMU's Transformer-XL
+ * training + sampling hot path.
+ *
+ * The reference (POZAlabs/ComMU-code) is pure Python on PyTorch: it has no FFI layer.  Each
+ * entry point below replaces the PyTorch op sequence at the cited reference lines
+ * (paths relative to the reference repository root) and is what a binding for that path
+ * would call; the ctypes binding a maintainer would add is shown in INTEGRATION.md and
+ * shipped as commu-code_amd/commu_amd/_lib.py.
+ *
+ * Conventions: plain device pointers + sizes, no framework types; every call enqueues work on
+ * `stream` and returns 0, a positive hipError_t, or -22 (EINVAL) for an unsupported shape; no
+ * call allocates, synchronises or throws.  "bf16" buffers are `void*` to 16-bit bfloat16.
+ * Activation rows are time-major, row m = t * B + b, exactly the reference's [T, B, *] layout.
+ */
+#ifndef COMMU_HIP_H
+#define COMMU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- GEMM (nn.Linear forward/backward: model.py:205,212,278,164,167,46; autograd of the same) */
+enum {
+    COMMU_EPI_BIAS = 1,      /* C += bias[n]                    (Linear bias, model.py:164,167,40) */
+    COMMU_EPI_RELU = 2,      /* C = max(C, 0)                   (nn.ReLU, model.py:165)            */
+    COMMU_EPI_RESID = 4,     /* C += resid[m, n] (bf16)         (w + attn_out / inp + core_out)    */
+    COMMU_EPI_RELUMASK = 8,  /* C = relu_mask[m,n] > 0 ? C : 0  (ReLU backward)                    */
+    COMMU_EPI_OUT_F32 = 16   /* C is fp32 (default bf16)                                           */
+};
+/* C[M,N] = A[M,K] . B[N,K]^T with fused epilogue.  K % 32 == 0, lda/ldb % 8 == 0. */
+int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
+                       int K, const float* bias, const void* resid, int ldr, const void* relu_mask,
+                       int ldm, int flags, hipStream_t stream);
+/* slabs[s][n,k] = sum_{m in slice s} A[m,n] * B[m,k]  (weight gradients dW = dY^T X).
+ * mode 1: LDS transpose reads (ds_read_b64_tr_b16); mode 0: 16-bit gathers. */
+int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc,
+                       size_t slab_stride, int M, int N, int K, int nslices, int mode, hipStream_t stream);
+/* dst[i] (+)= sum_s src[s*stride + i] */
+int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, size_t stride,
+                           int accumulate, hipStream_t stream);
+
+/* ---- embedding (AdaptiveEmbedding.forward, model.py:409-420) and its gradient */
+int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo, int ntok, int D,
+                    float scale, hipStream_t stream);
+int commu_embed_bwd(const int64_t* tok, const void* dX_bf16, int ldx, float* dE, int ntok, int D, int V,
+                    float scale, int accumulate, hipStream_t stream);
+/* sinusoid table by distance d: out[d] = [sin(d f) | cos(d f)]  (PositionalEmbedding, model.py:136-152) */
+int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, hipStream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm at model.py:171,214; applied :179,352) */
+int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, const float* beta, void* y, int ldy,
+                        float* mean, float* rstd, int rows, int D, float eps, hipStream_t stream);
+int commu_layernorm_bwd_nblocks(int rows);
+/* part: [nblocks][3][D] partial column sums of (dy*xhat, dy, dz) */
+int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const float* mean,
+                        const float* rstd, const float* gamma, void* dz, int lddz, float* part, int rows,
+                        int D, hipStream_t stream);
+/* out[c] += sum_r X[r,c]   (bias gradients) */
+int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
+int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
+
+/* ---- output layer loss (ProjectedAdaptiveLogSoftmax.forward, n_clusters == 0: model.py:64-73) */
+int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse, int rows,
+                 int V, hipStream_t stream);
+int commu_ce_bwd(const float* logits, int ldl, const int64_t* target, const float* lse, const float* g,
+                 void* dlogits_bf16, int ldd, int rows, int V, hipStream_t stream);
+/* out[0] = scale * mean(nll[target != pad])   (train.py:148-149); keeps the count in cnt_ws */
+int commu_masked_mean(const float* nll, const int64_t* target, int n, int pad, float scale, float* sum_ws,
+                      int* cnt_ws, float* out, hipStream_t stream);
+int commu_loss_grad(const int64_t* target, int n, int pad, const int* cnt_ws, float scale, float* g,
+                    hipStream_t stream);
+
+/* ---- optimiser (clip_grad_norm_ + optim.Adam, train.py:159-165,442) on flat fp32 buffers */
+int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out_norm, hipStream_t stream);
+int commu_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, float lr,
+                    float beta1, float beta2, float eps, int step, const float* gnorm, float clip,
+                    hipStream_t stream);
+int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
+int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);
+int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, int cols, hipStream_t stream);
+int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
+                             hipStream_t stream);
+int commu_copy_bf16(const void* src, void* dst, size_t n, hipStream_t stream);
+
+/* ---- relative-position attention with XL memory
+ * (RelPartialLearnableMultiHeadAttn.forward, model.py:313-345; _rel_shift :251-259; mask :549-574) */
+typedef struct commu_attn_desc {
+    const void* q;   /* bf16, row i: q + (i*B + b)*ld_qkv + h*DH, i in [0,T)   (current segment) */
+    const void* k;   /* bf16, row j: k + (j*B + b)*ld_qkv + h*DH, j in [0,T+M) (memory first)    */
+    const void* v;
+    const void* rd;  /* bf16 [T+M][ld_rd]: r_net(sinusoid(distance d)), distance d = i + M - j   */
+    const float* r_w_bias;          /* [H][DH]  (u) */
+    const float* r_r_bias;          /* [H][DH]  (v) */
+    const unsigned char* reset;     /* [B] reset_mems flags or NULL (model.py:574) */
+    int ld_qkv, ld_rd, ld_o;
+    int T, M, B, H, DH;
+    int same_length, sshift;        /* same_length mask: j <= i - sshift is masked (model.py:549-568) */
+    float scale;                    /* 1/sqrt(d_head), model.py:216 */
+} commu_attn_desc;
+
+/* vt: V transposed per head [B][H][DH][Jpad] (commu_transpose_heads). out: bf16 [T*B][ld_o];
+ * lse: fp32 [B][H][T]. */
+int commu_relattn_fwd(const commu_attn_desc* d, const void* vt, int Jpad, void* out, float* lse,
+                      hipStream_t stream);
+
+typedef struct commu_attn_bwd_desc {
+    const void* o;        /* forward output, bf16 [T*B][ld_o] */
+    const void* dout;     /* its gradient, same layout */
+    const float* lse;     /* [B][H][T] */
+    const float* delta;   /* [B][H][T]  (commu_attn_delta) */
+    const void* kt;       /* K^T      [B][H][DH][Jpad] */
+    const void* rdt;      /* Rd^T     [H][DH][Wr], column 128 + commu_attn_rdt_shift(M) + d */
+    const void* qut;      /* (q+u)^T  [B][H][DH][Tpad] */
+    const void* dot;      /* dO^T     [B][H][DH][Tpad] */
+    void* dq;             /* bf16 rows like q with ld_dqkv */
+    void* dk;             /* bf16 rows like k with ld_dqkv */
+    void* dv;
+    void* qv_out;         /* bf16 [T*B][H*DH]  (q + r_r_bias) */
+    void* dsk;            /* bf16 [H][T*B][ld_dsk], zero-initialised: dS indexed by distance */
+    float* du_part;       /* [B*ceil(T/64)][H*DH] column sums of the AC part of dq */
+    float* dvb_part;      /* same for the BD part */
+    int ld_dqkv, ld_dsk, Jpad, Tpad, Wr;
+} commu_attn_bwd_desc;
+int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
+int commu_attn_rdt_shift(int M);
+int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H, int DH,
+                     hipStream_t stream);
+/* dst[((b*H+h)*DH+f)*W + off + j] = src[(j*B+b)*ld + h*DH + f] (+ bias[h*DH+f]); zero elsewhere */
+int commu_transpose_heads(const void* src, int ld, const float* bias, void* dst, int J, int B, int H,
+                          int DH, int W, int off, hipStream_t stream);
+
+/* library identification */
+const char* commu_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMMU_HIP_H */

@@ -1,0 +1,331 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI
+(commu_amd.ops -> commu_amd._lib -> libcommu_hip.so), against the CPU oracle's math evaluated
+in fp32/fp64 on the same bf16-rounded inputs.
+
+Tolerances (stated per check): results stored as bf16 carry one rounding (2^-9 relative), fp32
+results differ from the oracle only by accumulation order -> `relerr` = max|a-b| / max|b|.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import xl_ref as X  # noqa: E402
+
+DEV = "cuda"
+BF16_TOL = 1.2e-2      # one or two bf16 roundings of O(1)-relative values
+F32_TOL = 2e-3         # fp32 outputs of bf16-input GEMMs / reductions (order only)
+
+
+def ops():
+    from commu_amd import ops as o
+    return o
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 64), (257, 729, 128), (64, 1536, 512), (1, 96, 64)])
+def test_gemm_nt_plain(M, N, K):
+    o = ops()
+    A, B = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))
+    ref = A.float() @ B.float().t()
+    out = o.gemm_nt(A.to(DEV), B.to(DEV), out_f32=True)
+    assert relerr(out, ref) < F32_TOL
+    out = o.gemm_nt(A.to(DEV), B.to(DEV))
+    assert out.dtype == torch.bfloat16 and relerr(out, ref) < BF16_TOL
+
+
+def test_gemm_nt_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (guide rule 16)."""
+    o = ops()
+    K = 64
+    A = bf(torch.eye(K))
+    B = bf(torch.arange(96 * K, dtype=torch.float32).reshape(96, K) % 251)
+    out = o.gemm_nt(A.to(DEV), B.to(DEV), out_f32=True)
+    assert torch.equal(out.cpu(), B.float().t())
+
+
+def test_gemm_nt_epilogues():
+    o = ops()
+    M, N, K = 200, 264, 96
+    A, B = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4))
+    bias, resid, act = rnd(N, seed=5), bf(rnd(M, N, seed=6)), bf(rnd(M, N, seed=7))
+    ref = A.float() @ B.float().t()
+    out = o.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), relu=True, out_f32=True)
+    assert relerr(out, torch.relu(ref + bias)) < F32_TOL
+    out = o.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), resid=resid.to(DEV), out_f32=True)
+    assert relerr(out, ref + bias + resid.float()) < F32_TOL
+    out = o.gemm_nt(A.to(DEV), B.to(DEV), relu_mask=act.to(DEV), out_f32=True)
+    assert relerr(out, ref * (act.float() > 0)) < F32_TOL
+    # strided views (column slices of wider buffers)
+    wide = torch.zeros(M, 400, dtype=torch.bfloat16, device=DEV)
+    o.gemm_nt(A.to(DEV), B.to(DEV), out=wide[:, 100:100 + N])
+    assert relerr(wide[:, 100:100 + N], ref) < BF16_TOL and float(wide[:, :100].abs().max()) == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 256, 192), (333, 136, 64), (4096, 768, 64), (50, 8, 8)])
+def test_gemm_tn(M, N, K, mode):
+    o = ops()
+    A, B = bf(rnd(M, N, seed=8)), bf(rnd(M, K, seed=9))
+    ref = A.float().t() @ B.float()
+    out = torch.zeros(N, K, device=DEV)
+    o.gemm_tn(A.to(DEV), B.to(DEV), out, mode=mode)
+    assert relerr(out, ref) < F32_TOL
+    o.gemm_tn(A.to(DEV), B.to(DEV), out, accumulate=True, mode=mode)
+    assert relerr(out, 2 * ref) < F32_TOL
+
+
+def test_gemm_tn_asymmetric():
+    o = ops()
+    M, N, K = 32, 128, 128
+    A = torch.zeros(M, N)
+    B = torch.zeros(M, K)
+    for m in range(M):
+        A[m, (3 * m) % N] = 1.0
+        B[m, (5 * m + 1) % K] = float(m + 1)
+    ref = A.t() @ B
+    for mode in (0, 1):
+        out = torch.zeros(N, K, device=DEV)
+        o.gemm_tn(bf(A).to(DEV), bf(B).to(DEV), out, mode=mode)
+        assert torch.equal(out.cpu(), ref), f"mode {mode}"
+
+
+# ---------------------------------------------------------------------------------------------
+def test_embed_fwd_bwd():
+    o = ops()
+    V, D, n = 729, 128, 700
+    E = rnd(V, D, seed=10)
+    tok = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(11))
+    tok[:40] = 5                                   # heavy collisions
+    out = o.embed_fwd(tok.to(DEV), E.to(DEV))
+    assert relerr(out, E[tok] * math.sqrt(D)) < BF16_TOL
+    dX = bf(rnd(n, D, seed=12))
+    ref = torch.zeros(V, D).index_add_(0, tok, dX.float()) * math.sqrt(D)
+    dE = torch.ones(V, D, device=DEV)
+    o.embed_bwd(tok.to(DEV), dX.to(DEV), dE, accumulate=True)
+    assert relerr(dE - 1, ref) < 1e-5
+    o.embed_bwd(tok.to(DEV), dX.to(DEV), dE, accumulate=False)
+    assert relerr(dE, ref) < 1e-5
+
+
+def test_posemb_distance_order():
+    o = ops()
+    K, D = 37, 64
+    inv_freq = 1.0 / (10000 ** (torch.arange(0.0, D, 2.0) / D))
+    out = o.posemb(inv_freq.to(DEV), K, D)
+    ref = X.sinusoid_table(K, D).flip(0)          # reference row k is distance K-1-k
+    assert float((out.float().cpu() - ref).abs().max()) < 8e-3     # bf16 rounding of values in [-1,1]
+
+
+@pytest.mark.parametrize("rows,D", [(5, 64), (300, 128), (1000, 512), (130, 1024)])
+def test_layernorm_fwd_bwd(rows, D):
+    o = ops()
+    z = bf(rnd(rows, D, seed=13) * 2 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=14), 0.1 * rnd(D, seed=15)
+    y, mean, rstd = o.layernorm_fwd(z.to(DEV), gamma.to(DEV), beta.to(DEV))
+    zf = z.float().requires_grad_(True)
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = X.layer_norm(zf, gp, bp)
+    assert relerr(y, ref) < BF16_TOL
+    assert relerr(mean, zf.detach().mean(-1)) < 1e-4
+    dy = bf(rnd(rows, D, seed=16))
+    ref.backward(dy.float())
+    dz, part = o.layernorm_bwd(dy.to(DEV), z.to(DEV), mean, rstd, gamma.to(DEV))
+    assert relerr(dz, zf.grad) < BF16_TOL
+    sums = part.sum(0)
+    assert relerr(sums[0], gp.grad) < 2e-3
+    assert relerr(sums[1], bp.grad) < 2e-3
+    assert relerr(sums[2], dz.float().sum(0)) < 2e-3
+
+
+def test_colsum():
+    o = ops()
+    Xb = bf(rnd(777, 1000, seed=17))
+    out = torch.ones(1000, device=DEV)
+    o.colsum(Xb.to(DEV), out)
+    assert relerr(out - 1, Xb.float().sum(0)) < 1e-3
+    Xf = rnd(100, 40, seed=18)
+    out = torch.zeros(40, device=DEV)
+    o.colsum(Xf.to(DEV), out)
+    assert relerr(out, Xf.sum(0)) < 1e-5
+
+
+def test_ce_fwd_bwd():
+    o = ops()
+    rows, V, ld = 300, 729, 768
+    logits = torch.full((rows, ld), 1e4)           # pad columns hold garbage that must be ignored
+    logits[:, :V] = rnd(rows, V, seed=19) * 3
+    target = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(20))
+    nll, lse = o.ce_fwd(logits.to(DEV), target.to(DEV), V)
+    lg = logits[:, :V].clone().requires_grad_(True)
+    ref = torch.logsumexp(lg, -1) - lg.gather(1, target[:, None]).squeeze(1)
+    assert relerr(nll, ref) < 1e-5
+    g = rnd(rows, seed=21).abs()
+    ref.backward(g)
+    dl = o.ce_bwd(logits.to(DEV), target.to(DEV), lse, g.to(DEV), V)
+    assert relerr(dl[:, :V], lg.grad) < BF16_TOL
+    assert float(dl[:, V:].abs().max()) == 0.0
+
+
+def test_masked_mean_and_grad():
+    o = ops()
+    n = 1000
+    nll = rnd(n, seed=22).abs()
+    target = torch.randint(0, 5, (n,), generator=torch.Generator().manual_seed(23))
+    ws_sum, ws_cnt = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV, dtype=torch.int32)
+    out = torch.zeros(1, device=DEV)
+    o.masked_mean(nll.to(DEV), target.to(DEV), 0, 0.25, ws_sum, ws_cnt, out)
+    ref = nll[target != 0].mean() * 0.25
+    assert abs(float(out) - float(ref)) < 1e-5
+    g = torch.empty(n, device=DEV)
+    o.loss_grad(target.to(DEV), 0, ws_cnt, 0.25, g)
+    refg = (target != 0).float() * 0.25 / float((target != 0).sum())
+    assert relerr(g, refg) < 1e-6
+
+
+def test_adam_and_grad_norm_match_oracle():
+    o = ops()
+    n = 10007
+    p0, g0 = rnd(n, seed=24), rnd(n, seed=25) * 0.1
+    p = {"w": p0.clone()}
+    st = X.adam_init(p)
+    pd, gd = p0.to(DEV).clone(), g0.to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    part, gn = torch.empty(256, device=DEV), torch.empty(1, device=DEV)
+    for step in range(1, 4):
+        total, coef = X.clip_coef([g0], 0.25)
+        X.adam_update(p, {"w": g0 * coef}, st, 1e-2)
+        o.grad_norm(gd, part, gn)
+        assert abs(float(gn) - float(total)) < 1e-4 * float(total)
+        o.adam_step(pd, gd, m, v, pb, 1e-2, step, gnorm=gn, clip=0.25)
+        assert relerr(pd, p["w"]) < 1e-6
+        assert relerr(pb, p["w"]) < 5e-3
+
+
+def test_transposes():
+    o = ops()
+    x = rnd(100, 72, seed=26)
+    assert torch.equal(o.transpose_to_bf16(x.to(DEV)).cpu(), bf(x).t())
+    assert torch.equal(o.transpose_to_bf16(bf(x).to(DEV)).cpu(), bf(x).t())
+    J, B, H, DH, W = 21, 3, 2, 32, 64
+    src = bf(rnd(J * B, 3 * H * DH, seed=27))
+    bias = rnd(H * DH, seed=28)
+    out = o.transpose_heads(src.to(DEV)[:, H * DH:2 * H * DH], J, B, H, DH, W, off=5, bias=bias.to(DEV))
+    ref = torch.zeros(B, H, DH, W)
+    blk = (src[:, H * DH:2 * H * DH].float() + bias).view(J, B, H, DH)
+    ref[:, :, :, 5:5 + J] = blk.permute(1, 2, 3, 0)
+    assert relerr(out, ref) < BF16_TOL and float(out[..., :5].abs().max()) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+def attn_reference(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len):
+    """Oracle math (oracle/xl_ref.py) on fp32 copies of the bf16 inputs; rd is distance-indexed."""
+    K = T + M
+    r = rd.view(K, H, DH).flip(0)                  # reference row m is distance K-1-m
+    S = X.rel_attention_scores(q.view(T, B, H, DH), k.view(K, B, H, DH), r, u.view(H, DH), vb.view(H, DH))
+    S = S * (1.0 / math.sqrt(DH))
+    mask = X.attn_mask(T, M, B, reset, same_length, mem_len)
+    S = S.masked_fill(mask[:, None], float("-inf"))
+    A = torch.softmax(S, dim=3)
+    o = torch.einsum("bnij,jbnd->ibnd", A, v.view(K, B, H, DH)).reshape(T * B, H * DH)
+    lse = torch.logsumexp(S, dim=3)
+    return o, lse
+
+
+ATTN_CASES = [
+    # T, M, B, H, DH, same_length, mem_len, reset_col
+    (64, 0, 2, 2, 64, False, 0, None),
+    (128, 0, 1, 2, 32, False, 0, None),
+    (12, 16, 3, 2, 32, False, 16, 1),
+    (100, 60, 2, 2, 64, False, 64, 0),
+    (16, 16, 2, 2, 64, True, 16, None),
+    (70, 130, 2, 1, 64, True, 150, 1),
+    (1, 77, 2, 2, 32, True, 4146, None),
+    (200, 0, 1, 1, 64, False, 0, None),
+]
+
+
+def make_attn_inputs(T, M, B, H, DH, seed):
+    K = T + M
+    qkv = bf(rnd(K * B, 3 * H * DH, seed=seed) * 0.7)
+    rd = bf(rnd(K, H * DH, seed=seed + 1) * 0.7)
+    u, vb = rnd(H * DH, seed=seed + 2) * 0.3, rnd(H * DH, seed=seed + 3) * 0.3
+    return qkv, rd, u, vb
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_relattn_fwd(case):
+    o = ops()
+    T, M, B, H, DH, sl, mem_len, rc = case
+    K = T + M
+    qkv, rd, u, vb = make_attn_inputs(T, M, B, H, DH, 30)
+    reset = None
+    if rc is not None:
+        reset = torch.zeros(B, dtype=torch.bool)
+        reset[rc] = True
+    HD = H * DH
+    qf, kf, vf = qkv[M * B:, :HD].float(), qkv[:, HD:2 * HD].float(), qkv[:, 2 * HD:].float()
+    ref_o, ref_lse = attn_reference(qf, kf, vf, rd.float(), u, vb, reset, T, M, B, H, DH, sl, mem_len)
+    g = qkv.to(DEV)
+    rst = None if reset is None else reset.to(torch.uint8).to(DEV)
+    out, lse, _ = o.relattn_fwd(g[M * B:, :HD], g[:, HD:2 * HD], g[:, 2 * HD:], rd.to(DEV), u.to(DEV), vb.to(DEV),
+                                rst, T, M, B, H, DH, sl, mem_len)
+    assert relerr(out, ref_o) < BF16_TOL
+    assert float((lse.cpu() - ref_lse).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_relattn_bwd(case):
+    o = ops()
+    T, M, B, H, DH, sl, mem_len, rc = case
+    K = T + M
+    HD = H * DH
+    qkv, rd, u, vb = make_attn_inputs(T, M, B, H, DH, 40)
+    reset = None
+    if rc is not None:
+        reset = torch.zeros(B, dtype=torch.bool)
+        reset[rc] = True
+    leaf = qkv.float().requires_grad_(True)
+    rdl, ul, vl = rd.float().requires_grad_(True), u.clone().requires_grad_(True), vb.clone().requires_grad_(True)
+    ref_o, _ = attn_reference(leaf[M * B:, :HD], leaf[:, HD:2 * HD], leaf[:, 2 * HD:], rdl, ul, vl, reset, T, M, B,
+                              H, DH, sl, mem_len)
+    dout = bf(rnd(T * B, HD, seed=41))
+    ref_o.backward(dout.float())
+
+    g = qkv.to(DEV)
+    rst = None if reset is None else reset.to(torch.uint8).to(DEV)
+    q, k, v = g[M * B:, :HD], g[:, HD:2 * HD], g[:, 2 * HD:]
+    out, lse, _ = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len)
+    dqkv = torch.zeros_like(g)
+    drd = torch.zeros(K, HD, device=DEV)
+    du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
+    o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
+                  dout.to(DEV), lse, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+    gref = leaf.grad
+    tol = 2.5e-2          # bf16 P/dS operands + bf16 outputs
+    assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol, "dq"
+    assert relerr(dqkv[:, HD:2 * HD], gref[:, HD:2 * HD]) < tol, "dk"
+    assert relerr(dqkv[:, 2 * HD:], gref[:, 2 * HD:]) < tol, "dv"
+    assert float(dqkv[:M * B, :HD].abs().max()) == 0 if M > 0 else True
+    assert relerr(drd, rdl.grad) < tol, "drd"
+    assert relerr(du, ul.grad) < tol, "du"
+    assert relerr(dvb, vl.grad) < tol, "dvb"
