@@ -1,0 +1,32 @@
+"""Device-side loss reduction used by the training loop (reference train.py:148-149):
+`loss[target != pad].mean()` without the boolean-index host sync."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class _MaskedMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nll, target, pad_id, scale):
+        dev = nll.device
+        ws_sum = torch.empty(1, device=dev, dtype=torch.float32)
+        ws_cnt = torch.empty(1, device=dev, dtype=torch.int32)
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        n = nll.contiguous().view(-1)
+        t = target.contiguous().view(-1)
+        ops.masked_mean(n, t, int(pad_id), float(scale), ws_sum, ws_cnt, out)
+        ctx.t, ctx.cnt, ctx.pad, ctx.scale, ctx.shape = t, ws_cnt, int(pad_id), float(scale), nll.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = torch.empty(ctx.t.numel(), device=ctx.t.device, dtype=torch.float32)
+        ops.loss_grad(ctx.t, ctx.pad, ctx.cnt, ctx.scale, g)
+        return (g * gout).view(ctx.shape), None, None, None
+
+
+def masked_mean(nll, target, pad_id=0, scale=1.0):
+    """scale * mean(nll[target != pad_id])  -- scale = 1 / batch_chunk in the training loop."""
+    return _MaskedMean.apply(nll, target, pad_id, scale)

@@ -1,0 +1,470 @@
+"""MemTransformerLM on MI355X: the reference's class API over hand-written HIP kernels.
+
+Mirrors `commu.model.model.MemTransformerLM` (reference commu/model/model.py:423-693): same
+constructor `(cfg, vocab)`, same `forward / forward_generate / reset_length / init_mems`, same
+sub-module and state_dict names (so reference checkpoints load and `model.apply(weights_init)`
+works), but the arithmetic of a whole forward (and its backward) is ONE schedule of kernel
+launches from libcommu_hip.so -- no per-op autograd tape, activations in bf16, fp32 master
+weights / LayerNorm statistics / loss, flat parameter + gradient buffers.
+
+There is no CPU path: calling the model with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import CommuHipError
+
+BF16, F32 = torch.bfloat16, torch.float32
+VPAD = 768          # logits leading dimension (729 -> 768)
+
+
+def _no_direct_forward(self, *a, **kw):
+    raise CommuHipError(f"{type(self).__name__} is a parameter holder; call MemTransformerLM.forward")
+
+
+class AdaptiveEmbedding(nn.Module):
+    """Parameter holder with the reference's names (model.py:380-407); d_proj == d_embed only."""
+
+    def __init__(self, n_token, d_embed, d_proj):
+        super().__init__()
+        if d_proj != d_embed:
+            raise CommuHipError("d_proj != d_embed is dead code in the reference and is not built")
+        self.n_token, self.d_embed, self.d_proj = n_token, d_embed, d_proj
+        self.cutoffs = [n_token]
+        self.emb_scale = d_proj ** 0.5
+        self.emb_layers = nn.ModuleList([nn.Embedding(n_token, d_embed, sparse=False)])
+        self.emb_projs = nn.ParameterList()
+
+    forward = _no_direct_forward
+
+
+class ProjectedAdaptiveLogSoftmax(nn.Module):
+    """Parameter holder for the output layer (model.py:6-42), n_clusters == 0 branch only."""
+
+    def __init__(self, n_token, d_embed, d_proj):
+        super().__init__()
+        self.n_token, self.d_embed, self.d_proj = n_token, d_embed, d_proj
+        self.cutoffs = [n_token]
+        self.cutoff_ends = [0, n_token]
+        self.shortlist_size = n_token
+        self.n_clusters = 0
+        self.head_size = n_token
+        self.out_layers = nn.ModuleList([nn.Linear(d_embed, n_token)])
+        self.out_projs = nn.ParameterList()
+
+    forward = _no_direct_forward
+
+
+class PositionalEmbedding(nn.Module):
+    def __init__(self, demb):
+        super().__init__()
+        self.demb = demb
+        inv_freq = 1 / (10000 ** (torch.arange(0.0, demb, 2.0) / demb))     # model.py:142
+        self.register_buffer("inv_freq", inv_freq)
+
+    forward = _no_direct_forward
+
+
+class PositionwiseFF(nn.Module):
+    def __init__(self, d_model, d_inner, dropout):
+        super().__init__()
+        self.d_model, self.d_inner, self.dropout = d_model, d_inner, dropout
+        self.CoreNet = nn.Sequential(nn.Linear(d_model, d_inner), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                                     nn.Linear(d_inner, d_model), nn.Dropout(dropout))   # model.py:163-169
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    forward = _no_direct_forward
+
+
+class RelPartialLearnableMultiHeadAttn(nn.Module):
+    def __init__(self, n_head, d_model, d_head, dropout, dropatt=0, tgt_len=None, mem_len=None):
+        super().__init__()
+        self.n_head, self.d_model, self.d_head, self.dropout = n_head, d_model, d_head, dropout
+        self.qkv_net = nn.Linear(d_model, 3 * n_head * d_head, bias=False)     # model.py:205
+        self.drop = nn.Dropout(dropout)
+        self.dropatt = nn.Dropout(dropatt)
+        self.o_net = nn.Linear(n_head * d_head, d_model, bias=False)           # model.py:212
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.scale = 1 / (d_head ** 0.5)
+        self.r_net = nn.Linear(d_model, n_head * d_head, bias=False)           # model.py:278
+
+    forward = _no_direct_forward
+
+
+class RelPartialLearnableDecoderLayer(nn.Module):
+    def __init__(self, n_head, d_model, d_head, d_inner, dropout, **kwargs):
+        super().__init__()
+        self.dec_attn = RelPartialLearnableMultiHeadAttn(n_head, d_model, d_head, dropout, **kwargs)
+        self.pos_ff = PositionwiseFF(d_model, d_inner, dropout)
+
+    forward = _no_direct_forward
+
+
+class _Saved:
+    """Activations of one forward call kept for its backward."""
+    __slots__ = ("T", "M", "B", "tokens", "target", "reset", "h", "cat", "qkv", "rd", "vec", "lse", "z1", "mu1",
+                 "rs1", "a", "hid", "z2", "mu2", "rs2", "pd", "hL", "logits", "ce_lse", "same_length", "mem_len")
+
+
+class _XLLoss(torch.autograd.Function):
+    """loss[T,B] = NLL of the whole network; backward runs the hand-written backward schedule."""
+
+    @staticmethod
+    def forward(ctx, model, data, target, reset, mems, *params):
+        loss, new_mems, saved = model._run_forward(data, target, reset, mems, need_grad=True)
+        ctx.model, ctx.saved = model, saved
+        if new_mems is None:
+            new_mems = torch.empty(0, device=data.device)
+        ctx.mark_non_differentiable(new_mems)
+        return loss, new_mems
+
+    @staticmethod
+    def backward(ctx, dloss, _dmems):
+        model, saved = ctx.model, ctx.saved
+        ctx.saved = None
+        if saved is None:
+            raise CommuHipError("backward called twice on the same forward")
+        grads = model._run_backward(saved, dloss.contiguous())
+        return (None, None, None, None, None) + grads
+
+
+class MemTransformerLM(nn.Module):
+    def __init__(self, cfg, vocab):
+        n_layer = cfg.MODEL.num_layers
+        n_head = cfg.MODEL.num_heads
+        d_model = cfg.MODEL.units
+        d_head = cfg.MODEL.units // cfg.MODEL.num_heads
+        d_inner = cfg.MODEL.inner_size
+        dropout = cfg.MODEL.dropout
+        dropatt = cfg.MODEL.attention_dropout
+        tgt_len = cfg.TRAIN.tgt_length
+        mem_len = cfg.TRAIN.mem_length
+        super().__init__()
+        self.cfg = cfg
+        self.n_token = len(vocab)
+        self.d_embed = d_model
+        self.d_model, self.n_head, self.d_head, self.d_inner = d_model, n_head, d_head, d_inner
+        self.word_emb = AdaptiveEmbedding(self.n_token, d_model, d_model)
+        self.drop = nn.Dropout(dropout)
+        self.n_layer = n_layer
+        self.tgt_len, self.mem_len = tgt_len, mem_len
+        self.max_klen = tgt_len + mem_len
+        self.layers = nn.ModuleList([
+            RelPartialLearnableDecoderLayer(n_head, d_model, d_head, d_inner, dropout, tgt_len=tgt_len,
+                                            mem_len=mem_len, dropatt=dropatt) for _ in range(n_layer)])
+        self.crit = ProjectedAdaptiveLogSoftmax(self.n_token, d_model, d_model)
+        for i in range(len(self.crit.out_layers)):                     # weight tying, model.py:480-481
+            self.crit.out_layers[i].weight = self.word_emb.emb_layers[i].weight
+        self.same_length = cfg.MODEL.same_length
+        self.clamp_len = cfg.MODEL.clamp_len
+        self.detach_mems_grad = True
+        self.pos_emb = PositionalEmbedding(d_model)
+        self.r_w_bias = nn.Parameter(torch.Tensor(n_head, d_head))      # model.py:491-492 (uninitialised)
+        self.r_r_bias = nn.Parameter(torch.Tensor(n_head, d_head))
+        if self.clamp_len > 0:
+            raise CommuHipError("clamp_len > 0 is not used by the reference configs and is not built")
+        if d_model % 64 or d_inner % 64 or d_head not in (32, 64) or self.n_token > VPAD:
+            raise CommuHipError(f"unsupported shape: d_model={d_model} d_inner={d_inner} d_head={d_head} "
+                                "(this build needs d_model, d_inner % 64 == 0 and d_head in {32, 64})")
+        # gradient delivery: "direct" writes into the flat gradient buffer that p.grad aliases;
+        # "autograd" returns the gradients to autograd (compatible with torch DDP hooks).
+        self.grad_mode = "direct"
+        self._flat = None
+
+    # ------------------------------------------------------------------ reference API
+    def reset_length(self, tgt_len, mem_len):                            # model.py:494-496
+        self.tgt_len = tgt_len
+        self.mem_len = mem_len
+
+    def init_mems(self, n_layers):                                       # model.py:498-505
+        if self.mem_len > 0:
+            param = next(self.parameters())
+            return torch.empty(n_layers + 1, 0, dtype=BF16, device=param.device)
+        return None
+
+    def forward(self, data, target, reset_mems, mems):                   # model.py:678-693
+        if mems is None:
+            mems = self.init_mems(self.n_layer)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self._ensure_flat()
+            loss, new_mems = _XLLoss.apply(self, data, target, reset_mems, mems, *self._flat["params"])
+            if mems is None:
+                new_mems = None
+            return loss, new_mems
+        loss, new_mems, _ = self._run_forward(data, target, reset_mems, mems, need_grad=False)
+        return loss, new_mems
+
+    def forward_generate(self, data, mems):                              # model.py:606-628
+        if mems is None:
+            mems = self.init_mems(self.n_layer)
+        assert self.crit.n_clusters == 0
+        with torch.no_grad():
+            logits, new_mems, _ = self._run_forward(data, None, None, mems, need_grad=False, want_logits=True)
+        return logits, new_mems
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _param_list(self):
+        return [p for _, p in self.named_parameters()]
+
+    def _ensure_flat(self):
+        """fp32 master parameters / gradients live in two flat device buffers that the individual
+        nn.Parameters alias; bf16 shadows (W and W^T) are refreshed when any parameter changed."""
+        params = self._param_list()
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise CommuHipError("MemTransformerLM runs on an MI355X only: move it with .to('cuda') "
+                                "(there is no CPU fallback)")
+        fl = self._flat
+        ok = fl is not None and fl["dev"] == dev and all(
+            p.data_ptr() == fl["p"].data_ptr() + 4 * off for p, off in zip(params, fl["offs"]))
+        if not ok:
+            offs, total = [], 0
+            for p in params:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64
+            flat_p = torch.zeros(total, device=dev, dtype=F32)
+            flat_g = torch.zeros(total, device=dev, dtype=F32)
+            for p, off in zip(params, offs):
+                if p.dtype != F32:
+                    raise CommuHipError("parameters must be fp32 (master weights)")
+                flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + p.numel()].view(p.shape)
+                if p.grad is not None:
+                    flat_g[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                    p.grad = flat_g[off:off + p.numel()].view(p.shape)
+            fl = {"dev": dev, "p": flat_p, "g": flat_g, "offs": offs, "params": params, "total": total,
+                  "bf16": torch.zeros(total, device=dev, dtype=BF16), "version": None, "shadow": {},
+                  "m": None, "v": None, "gnorm": torch.zeros(1, device=dev, dtype=F32),
+                  "gpart": torch.zeros(256, device=dev, dtype=F32)}
+            self._flat = fl
+            self._name_off = {n: o for (n, _), o in zip(self.named_parameters(), offs)}
+        ver = sum(p._version for p in params)
+        if fl["version"] != ver:
+            self._refresh_shadows()
+            fl["version"] = sum(p._version for p in params)
+        return fl
+
+    def _bf16_view(self, name, shape):
+        fl = self._flat
+        off = self._name_off[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return fl["bf16"][off:off + n].view(shape)
+
+    def _grad_view(self, name, shape):
+        fl = self._flat
+        off = self._name_off[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return fl["g"][off:off + n].view(shape)
+
+    def _refresh_shadows(self, cast=True):
+        """bf16 copy of every parameter (same offsets) + transposed bf16 weights for the dX GEMMs."""
+        fl = self._flat
+        if cast:
+            ops.cast_bf16(fl["p"], fl["bf16"])
+        D, DI, HD, V = self.d_model, self.d_inner, self.n_head * self.d_head, self.n_token
+        sh = fl["shadow"]
+        dev = fl["dev"]
+
+        def tr(key, name, shape, pad_cols=None):
+            w = self._bf16_view(name, shape)
+            cols = shape[0] if pad_cols is None else pad_cols
+            if key not in sh:
+                sh[key] = torch.zeros(shape[1], cols, device=dev, dtype=BF16)
+            ops.transpose_to_bf16(w, sh[key][:, :shape[0]])
+        tr("Et", "word_emb.emb_layers.0.weight", (V, D), VPAD)
+        for i in range(self.n_layer):
+            pre = f"layers.{i}."
+            tr(f"qkv_t{i}", pre + "dec_attn.qkv_net.weight", (3 * HD, D))
+            tr(f"o_t{i}", pre + "dec_attn.o_net.weight", (D, HD))
+            tr(f"w1_t{i}", pre + "pos_ff.CoreNet.0.weight", (DI, D))
+            tr(f"w2_t{i}", pre + "pos_ff.CoreNet.3.weight", (D, DI))
+
+    # ------------------------------------------------------------------ forward schedule
+    def _weights(self, i):
+        D, DI, HD = self.d_model, self.d_inner, self.n_head * self.d_head
+        pre = f"layers.{i}."
+        bv = self._bf16_view
+        return {"qkv": bv(pre + "dec_attn.qkv_net.weight", (3 * HD, D)),
+                "o": bv(pre + "dec_attn.o_net.weight", (D, HD)),
+                "r": bv(pre + "dec_attn.r_net.weight", (HD, D)),
+                "w1": bv(pre + "pos_ff.CoreNet.0.weight", (DI, D)),
+                "w2": bv(pre + "pos_ff.CoreNet.3.weight", (D, DI))}
+
+    def _run_forward(self, data, target, reset, mems, need_grad, want_logits=False):
+        fl = self._ensure_flat()
+        dev = fl["dev"]
+        if not data.is_cuda:
+            raise CommuHipError("inputs must be GPU tensors (no CPU fallback)")
+        T, B = data.shape
+        D, DI, H, DH, L, V = self.d_model, self.d_inner, self.n_head, self.d_head, self.n_layer, self.n_token
+        HD = H * DH
+        M = 0 if mems is None or mems.numel() == 0 else mems.shape[1]
+        K = T + M
+        TB = T * B
+        tokens = data.contiguous().view(-1)
+        rst = None
+        if reset is not None and M > 0:
+            rst = reset.to(device=dev, dtype=torch.uint8).contiguous()
+        lay = [self.layers[i] for i in range(L)]
+        sv = _Saved() if need_grad else None
+
+        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight)            # K1
+        pd = ops.posemb(self.pos_emb.inv_freq, K, D)                             # K2 (distance order)
+        hids = [h]
+        if need_grad:
+            sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
+            sv.same_length, sv.mem_len = bool(self.same_length), int(self.mem_len)
+            for k in ("h", "cat", "qkv", "rd", "vec", "lse", "z1", "mu1", "rs1", "a", "hid", "z2", "mu2", "rs2"):
+                setattr(sv, k, [])
+        u, vb = self.r_w_bias, self.r_r_bias
+        for i in range(L):
+            w = self._weights(i)
+            qkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
+            cat = None
+            if M > 0:                                                            # K4 over [mem; h] (model.py:283-288)
+                cat = mems[i].reshape(M * B, D)
+                if cat.dtype != BF16:
+                    cat = cat.to(BF16)
+                ops.gemm_nt(cat, w["qkv"][HD:], out=qkv[:M * B, HD:])
+            ops.gemm_nt(h, w["qkv"], out=qkv[M * B:])
+            rd = ops.gemm_nt(pd, w["r"])                                         # K5
+            vec, lse, _ = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
+                                          T, M, B, H, DH, bool(self.same_length), int(self.mem_len))   # K6
+            z1 = ops.gemm_nt(vec, w["o"], resid=h)                               # K7
+            a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)
+            hid = ops.gemm_nt(a, w["w1"], bias=lay[i].pos_ff.CoreNet[0].bias, relu=True)     # K8
+            z2 = ops.gemm_nt(hid, w["w2"], bias=lay[i].pos_ff.CoreNet[3].bias, resid=a)
+            y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias)
+            if need_grad:
+                sv.h.append(h); sv.cat.append(cat); sv.qkv.append(qkv); sv.rd.append(rd); sv.vec.append(vec)
+                sv.lse.append(lse); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1); sv.a.append(a)
+                sv.hid.append(hid); sv.z2.append(z2); sv.mu2.append(mu2); sv.rs2.append(rs2)
+            h = y
+            hids.append(h)
+
+        new_mems = self._update_mems(hids, mems, M, T, B)                        # K9
+        logits = torch.empty(TB, VPAD, device=dev, dtype=F32)                    # K10 / K14
+        ops.gemm_nt(h, self._bf16_view("word_emb.emb_layers.0.weight", (V, D)), out=logits[:, :V],
+                    bias=self.crit.out_layers[0].bias)
+        if want_logits:
+            return logits.view(T, B, VPAD)[:, :, :V], new_mems, None
+        tgt = target.contiguous().view(-1)
+        nll, ce_lse = ops.ce_fwd(logits, tgt, V)
+        if need_grad:
+            sv.hL, sv.logits, sv.ce_lse, sv.target = h, logits, ce_lse, tgt
+        return nll.view(T, B), new_mems, sv
+
+    def _update_mems(self, hids, mems, M, T, B):                                 # model.py:507-538
+        if mems is None:
+            return None
+        with torch.no_grad():
+            end = M + T
+            beg = max(0, end - self.mem_len)
+            n = end - beg
+            out = torch.empty(len(hids), n, B, self.d_model, device=hids[0].device, dtype=BF16)
+            for i, hcur in enumerate(hids):
+                hv = hcur.view(T, B, self.d_model)
+                if beg >= M:
+                    out[i].copy_(hv[beg - M:])
+                else:
+                    out[i, :M - beg].copy_(mems[i][beg:])
+                    out[i, M - beg:].copy_(hv)
+            return out
+
+    # ------------------------------------------------------------------ backward schedule
+    def _run_backward(self, sv, dloss):
+        fl = self._ensure_flat()
+        dev = fl["dev"]
+        params = fl["params"]
+        direct = self.grad_mode == "direct"
+        if direct:
+            fresh = all(p.grad is None for p in params)
+            aliased = all(p.grad is not None and p.grad.data_ptr() == fl["g"].data_ptr() + 4 * off
+                          for p, off in zip(params, fl["offs"]))
+            if fresh:
+                fl["g"].zero_()
+                for p, off in zip(params, fl["offs"]):
+                    p.grad = fl["g"][off:off + p.numel()].view(p.shape)
+            elif not aliased:
+                direct = False
+        G = fl["g"]
+        if not direct:
+            G = torch.zeros_like(fl["g"])
+        gname = {n: o for n, o in self._name_off.items()}
+
+        def gv(name, shape):
+            n = 1
+            for s in shape:
+                n *= s
+            return G[gname[name]:gname[name] + n].view(shape)
+
+        T, M, B = sv.T, sv.M, sv.B
+        D, DI, H, DH, L, V = self.d_model, self.d_inner, self.n_head, self.d_head, self.n_layer, self.n_token
+        HD, K, TB = H * DH, T + M, T * B
+        sh = fl["shadow"]
+        g = dloss.reshape(-1).to(F32)
+        dlogits = ops.ce_bwd(sv.logits, sv.target, sv.ce_lse, g, V)             # [TB, 768] bf16, pad cols 0
+        ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)))
+        gE = gv("word_emb.emb_layers.0.weight", (V, D))
+        self._tn_acc(dlogits, sv.hL, gE, rows=V)
+        dy = ops.gemm_nt(dlogits, sh["Et"])                                      # [TB, D]
+        gu, gvb = gv("r_w_bias", (HD,)), gv("r_r_bias", (HD,))
+        for i in range(L - 1, -1, -1):
+            pre = f"layers.{i}."
+            lay = self.layers[i]
+            dz2, part = ops.layernorm_bwd(dy, sv.z2[i], sv.mu2[i], sv.rs2[i], lay.pos_ff.layer_norm.weight)
+            ops.colsum(part[:, 0], gv(pre + "pos_ff.layer_norm.weight", (D,)))
+            ops.colsum(part[:, 1], gv(pre + "pos_ff.layer_norm.bias", (D,)))
+            ops.colsum(part[:, 2], gv(pre + "pos_ff.CoreNet.3.bias", (D,)))
+            self._tn_acc(dz2, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (D, DI)))
+            dhid = ops.gemm_nt(dz2, sh[f"w2_t{i}"], relu_mask=sv.hid[i])
+            self._tn_acc(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DI, D)))
+            ops.colsum(dhid, gv(pre + "pos_ff.CoreNet.0.bias", (DI,)))
+            da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
+            dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight)
+            ops.colsum(part[:, 0], gv(pre + "dec_attn.layer_norm.weight", (D,)))
+            ops.colsum(part[:, 1], gv(pre + "dec_attn.layer_norm.bias", (D,)))
+            self._tn_acc(dz1, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (D, HD)))
+            dvec = ops.gemm_nt(dz1, sh[f"o_t{i}"])
+            qkv = sv.qkv[i]
+            dqkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
+            if M > 0:
+                dqkv[:M * B, :HD].zero_()
+            drd = torch.empty(K, HD, device=dev, dtype=F32)
+            ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], self.r_w_bias,
+                            self.r_r_bias, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
+                            sv.lse[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb)
+            self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HD, D)))
+            gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HD, D))
+            self._tn_acc(dqkv[M * B:], sv.h[i], gW)
+            if M > 0:
+                self._tn_acc(dqkv[:M * B, HD:], sv.cat[i], gW[HD:])
+            dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
+        ops.embed_bwd(sv.tokens, dy, gE, accumulate=True)
+        if direct:
+            return tuple(None for _ in params)
+        return tuple(G[off:off + p.numel()].view(p.shape) for p, off in zip(params, fl["offs"]))
+
+    def _tn_acc(self, dY, Xa, gW, rows=None):
+        """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads."""
+        N = dY.shape[1]
+        Kc = Xa.shape[1]
+        M = dY.shape[0]
+        ns = ops.tn_slices(M, N, Kc)
+        fl = self._flat
+        need = ns * N * Kc
+        if fl.get("slabs") is None or fl["slabs"].numel() < need:
+            fl["slabs"] = torch.empty(need, device=fl["dev"], dtype=F32)
+        ops.gemm_tn_raw(dY, Xa, fl["slabs"], ns)
+        nrows = N if rows is None else rows
+        ops.reduce_slabs(gW, fl["slabs"], nrows * Kc, ns, N * Kc, True)

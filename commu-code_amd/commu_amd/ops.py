@@ -92,6 +92,24 @@ def gemm_tn(A, B, out, *, accumulate=False, slabs=None, mode=None):
     return out
 
 
+def gemm_tn_raw(A, B, slabs, nslices, mode=None):
+    """slabs[s][N,K] = A[m-slice s]^T @ B[m-slice s]; reduce with reduce_slabs."""
+    lda, ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
+    M, N = A.shape
+    K = B.shape[1]
+    assert B.shape[0] == M and slabs.numel() >= nslices * N * K and slabs.dtype == F32
+    call("commu_gemm_tn_bf16", _p(A), lda, _p(B), ldb, _p(slabs), K, N * K, M, N, K, nslices,
+         TN_MODE if mode is None else mode, _s())
+    return slabs
+
+
+def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate):
+    """dst.view(-1)[:n] (+)= sum_s slabs[s*stride : s*stride + n]"""
+    assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() >= n
+    call("commu_reduce_slabs_f32", _p(dst), _p(slabs), n, nslabs, stride, 1 if accumulate else 0, _s())
+    return dst
+
+
 def embed_fwd(tok, E, out=None):
     ntok = tok.numel()
     D = E.shape[1]
@@ -181,6 +199,12 @@ def grad_norm(g, part, out):
 def adam_step(p, g, m, v, p_bf16, lr, step, gnorm=None, clip=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
     call("commu_adam_step", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, step,
          _p(gnorm), clip, _s())
+
+
+def scale_clip(g, gnorm, clip):
+    """g *= min(1, clip / (gnorm + 1e-6))   (torch.nn.utils.clip_grad_norm_, train.py:159-161)"""
+    call("commu_scale_clip_f32", _p(g), g.numel(), _p(gnorm), clip, _s())
+    return g
 
 
 def cast_bf16(x, out=None):

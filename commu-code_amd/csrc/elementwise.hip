@@ -319,6 +319,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+__global__ void scale_clip_kernel(float* __restrict__ g, size_t n, const float* __restrict__ gnorm, float clip) {
+    const float coef = fminf(1.f, clip / (gnorm[0] + 1e-6f));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        g[i] *= coef;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = f2bf(in[i]);
@@ -506,6 +512,14 @@ extern "C" int commu_adam_step(float* p, const float* g, float* m, float* v, voi
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
                        (bf16*)p_bf16, n, lr, beta1, beta2, eps, bc1, bc2, gnorm, clip);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, float clip, hipStream_t stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_clip_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, g, n, gnorm,
+                       clip);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -82,6 +82,8 @@ int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out
 int commu_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, float lr,
                     float beta1, float beta2, float eps, int step, const float* gnorm, float clip,
                     hipStream_t stream);
+/* g *= min(1, clip / (gnorm[0] + 1e-6)) */
+int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, float clip, hipStream_t stream);
 int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);
 int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, int cols, hipStream_t stream);

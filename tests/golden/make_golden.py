@@ -458,19 +458,22 @@ def g8_dataset():
         out[f"tr{i}_reset"], out[f"tr{i}_ntok"] = reset.numpy().copy(), np.array(ntok)
     out["tr_n"] = np.array(14)
     it = ds.get_iterator(3, 8, "cpu", "valid", False, seed=None)()
-    batches = list(it)
-    out["noshuf_n"] = np.array(len(batches))
-    for i, (data, target, reset, ntok) in enumerate(batches):
+    nb = 0      # the reference re-uses its batch tensors (.to("cpu") is a no-op): copy while iterating
+    for i, (data, target, reset, ntok) in enumerate(it):
         out[f"ns{i}_data"], out[f"ns{i}_target"] = data.numpy().copy(), target.numpy().copy()
         out[f"ns{i}_reset"], out[f"ns{i}_ntok"] = reset.numpy().copy(), np.array(ntok)
+        nb += 1
+    out["noshuf_n"] = np.array(nb)
     for ws in (1, 2):
         for rank in range(ws):
-            evs = list(ds.eval_iterator(4, 16, "cpu", "valid", local_rank=rank, world_size=ws)())
-            out[f"ev_ws{ws}_r{rank}_n"] = np.array(len(evs))
-            for i, (data, target, allreset, ntok) in enumerate(evs):
+            nb = 0
+            for i, (data, target, allreset, ntok) in enumerate(
+                    ds.eval_iterator(4, 16, "cpu", "valid", local_rank=rank, world_size=ws)()):
                 pre = f"ev_ws{ws}_r{rank}_{i}_"
                 out[pre + "data"], out[pre + "target"] = data.numpy().copy(), target.numpy().copy()
                 out[pre + "reset"], out[pre + "ntok"] = np.array(allreset), np.array(ntok)
+                nb += 1
+            out[f"ev_ws{ws}_r{rank}_n"] = np.array(nb)
     save("g8_dataset.npz", **out)
 
 

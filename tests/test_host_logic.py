@@ -1,0 +1,126 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no kernels):
+batch producer vs the reference's iterators (fixture g8_dataset), LR schedule, config surface,
+state_dict names."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from commu_amd.model.config_helper import get_cfg, get_default_cfg_inference, get_default_cfg_training
+from commu_amd.model.dataset import BaseVocab, ComMUDataset, synthetic_batch
+from commu_amd.optim import lr_lambda_factory
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def corpus_from_fixture(z):
+    out = {}
+    for split, key in (("train", "train"), ("valid", "val")):
+        lens = z[f"{key}_lens"]
+        ev = z[f"{key}_events"]
+        metas = z[f"{key}_meta"]
+        seqs, o = [], 0
+        for i, n in enumerate(lens):
+            seqs.append(np.concatenate([metas[i], ev[o:o + n]]))
+            o += n
+        out[split] = seqs
+    return out
+
+
+def test_train_iterator_matches_reference(golden_dir):
+    z = load(golden_dir, "g8_dataset.npz")
+    ds = ComMUDataset(None, None, sequences=corpus_from_fixture(z))
+    it = ds.get_iterator(4, 16, "cpu", "train", True, seed=1111)()
+    for i in range(int(z["tr_n"])):
+        data, target, reset, ntok = next(it)
+        assert np.array_equal(data.numpy(), z[f"tr{i}_data"]), i
+        assert np.array_equal(target.numpy(), z[f"tr{i}_target"]), i
+        assert np.array_equal(reset.numpy(), z[f"tr{i}_reset"]), i
+        assert ntok == int(z[f"tr{i}_ntok"])
+    batches = list(ds.get_iterator(3, 8, "cpu", "valid", False, seed=None)())
+    assert len(batches) == int(z["noshuf_n"])
+    for i, (data, target, reset, ntok) in enumerate(batches):
+        assert np.array_equal(data.numpy(), z[f"ns{i}_data"]) and np.array_equal(target.numpy(), z[f"ns{i}_target"])
+        assert np.array_equal(reset.numpy(), z[f"ns{i}_reset"]) and ntok == int(z[f"ns{i}_ntok"])
+
+
+def test_eval_iterator_rank_shards_match_reference(golden_dir):
+    z = load(golden_dir, "g8_dataset.npz")
+    ds = ComMUDataset(None, None, sequences=corpus_from_fixture(z))
+    for ws in (1, 2):
+        for rank in range(ws):
+            evs = list(ds.eval_iterator(4, 16, "cpu", "valid", local_rank=rank, world_size=ws)())
+            assert len(evs) == int(z[f"ev_ws{ws}_r{rank}_n"])
+            for i, (data, target, allreset, ntok) in enumerate(evs):
+                pre = f"ev_ws{ws}_r{rank}_{i}_"
+                assert np.array_equal(data.numpy(), z[pre + "data"]) and np.array_equal(target.numpy(), z[pre + "target"])
+                assert bool(allreset) == bool(z[pre + "reset"]) and ntok == int(z[pre + "ntok"])
+
+
+def test_npy_on_disk_format_roundtrip(golden_dir, tmp_path):
+    z = load(golden_dir, "g8_dataset.npz")
+    seqs = corpus_from_fixture(z)
+    for split, tag in (("train", "train"), ("valid", "val")):
+        metas = np.array([np.array(s[:11], dtype=object) for s in seqs[split]], dtype=object)
+        ev = np.empty(len(seqs[split]), dtype=object)
+        for i, s in enumerate(seqs[split]):
+            ev[i] = s[11:].astype(np.int16)
+        np.save(tmp_path / f"input_{tag}.npy", metas, allow_pickle=True)
+        np.save(tmp_path / f"target_{tag}.npy", ev, allow_pickle=True)
+    ds = ComMUDataset(str(tmp_path), None)
+    data, target, reset, ntok = next(ds.get_iterator(4, 16, "cpu", "train", True, seed=1111)())
+    assert np.array_equal(data.numpy(), z["tr0_data"]) and ntok == int(z["tr0_ntok"])
+    assert len(ds.vocab) == 729 and ds.vocab.pad_id == 0
+
+
+def test_lr_schedule_matches_reference(golden_dir):
+    z = load(golden_dir, "g8_optim.npz")
+    f = lr_lambda_factory(100, 0.004, 0.0001)
+    assert np.array_equal(np.array([f(s) for s in range(301)]), z["lr_lambda_0_300"])
+    assert np.array_equal(np.array([f(s) for s in (1000, 10000, 20000, 200000)]), z["lr_lambda_far"])
+    assert f(0) == 0.0 and lr_lambda_factory(0, 0.004, 0.0001)(0) == 1.0
+
+
+def test_config_surface():
+    cfg = get_default_cfg_training()
+    assert (cfg.MODEL.num_layers, cfg.MODEL.num_heads, cfg.MODEL.units, cfg.MODEL.inner_size) == (6, 10, 500, 1000)
+    assert (cfg.TRAIN.batch_size, cfg.TRAIN.batch_chunk, cfg.TRAIN.tgt_length, cfg.TRAIN.mem_length) == (256, 4, 128, 1024)
+    assert (cfg.TRAIN.lr, cfg.TRAIN.lr_min, cfg.TRAIN.warmup_step, cfg.TRAIN.clip) == (0.004, 0.0001, 100, 1.0)
+    assert (cfg.EVALUATE.batch_size, cfg.EVALUATE.tgt_length, cfg.EVALUATE.mem_length) == (10, 128, 2048)
+    with pytest.raises(AttributeError):
+        cfg.MODEL.units = 1
+    cfg.defrost()
+    cfg.MODEL.same_length = True
+    cfg.freeze()
+    inf = get_default_cfg_inference()
+    assert inf.MODEL.memory_length == 4146 and inf.GENERATION.generation_length == 4096
+    assert inf.SAMPLING.temperature == 0.95 and inf.SAMPLING.threshold == 32.0
+    b = get_cfg()
+    assert (b.MODEL.units, b.MODEL.num_heads, b.MODEL.inner_size, b.TRAIN.tgt_length) == (512, 8, 1024, 1024)
+
+
+def test_model_state_dict_names(golden_dir):
+    from commu_amd.model.model import MemTransformerLM
+    z = load(golden_dir, "g1_train_mem.npz")
+    L, H, D, DI, T, B, mem_len, sl = [int(x) for x in z["meta"][:8]]
+    m = MemTransformerLM(get_cfg(num_layers=L, num_heads=H, units=D, inner_size=DI, tgt_length=T, mem_length=mem_len),
+                         BaseVocab())
+    sd = m.state_dict()
+    ref = {k[3:]: z[k].shape for k in z.files if k.startswith("p::")}
+    assert set(sd) == set(ref) | {"crit.out_layers.0.weight"}
+    for k, shp in ref.items():
+        assert tuple(sd[k].shape) == shp, k
+    assert m.crit.out_layers[0].weight is m.word_emb.emb_layers[0].weight     # model.py:480-481
+    assert m.crit.n_clusters == 0
+    assert m.init_mems(L).shape == (L + 1, 0)
+    m.reset_length(1, 0)
+    assert m.init_mems(L) is None
+
+
+def test_synthetic_batch_shape():
+    d, t, r, n = synthetic_batch(16, 4, "cpu", seed=1)
+    assert d.shape == (16, 4) and n == 64 and int(d.min()) >= 2 and int(d.max()) < 729
+    assert torch.equal(d[1:], t[:-1]) and not bool(r.any())
