@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the ComMU Transformer-XL training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+one rank per GPU over RCCL.)  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1]): 6 layers, d_model 512, 8 heads (d_head 64), FFN 1024,
+tgt_len 1024, mem_len 0, 64 sequences per GPU (weak scaling), bf16 GEMM/attention operands with
+fp32 accumulation, fp32 master weights; one "step" = one optimiser step of the reference's
+train() loop (forward + backward of every micro-batch, global-norm clip, Adam, LR schedule) on a
+synthetic token batch already resident in HBM.  metric = non-pad target tokens per second over
+all ranks (the reference's own tokens/s definition, train.py:157,174,186).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "commu-code_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def fwd_flops_per_token(L, D, DI, T, M, V=729):
+    """F = L*[6D^2 + 4D^2*(M/T) + 2D^2 + 4*D*DI + 6*Kbar*D] + 2*D*V."""
+    kbar = M + (T + 1) / 2.0
+    return L * (6 * D * D + 4 * D * D * (M / T) + 2 * D * D + 4 * D * DI + 6 * kbar * D) + 2 * D * V
+
+
+def cpu_baseline(args):
+    """The oracle's train step (oracle/xl_ref.py, a restatement of the reference pinned by the
+    golden fixtures) timed on the host cores: same shape, micro-batch 2 (CPU tokens/s is roughly
+    batch independent), 1 warm-up + timed steps bounded to ~20 s."""
+    from oracle import xl_ref as X
+    torch.set_num_threads(os.cpu_count())
+    s = X.XLShape(args.layers, args.heads, args.d_model, args.d_inner)
+    p = X.init_params(s, 1)
+    st = X.adam_init(p)
+    Bc, T = 2, args.tgt_len
+    g = torch.Generator().manual_seed(0)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        stream = torch.randint(2, 729, (T + 1, Bc), generator=g)
+        t0 = time.time()
+        X.train_step(p, st, s, stream[:-1], stream[1:], torch.zeros(Bc, dtype=torch.bool), [None], batch_chunk=1,
+                     mem_len=args.mem_len, same_length=False, lr_now=1e-4, clip=1.0)
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > 25 and times:
+            break
+    per = sum(times) / len(times)
+    return {"value": round(Bc * T / per, 1), "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{len(times)} optimiser steps of the same model shape at batch {Bc} x tgt_len {T} "
+                      f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--d-model", dest="d_model", type=int, default=512)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--d-inner", dest="d_inner", type=int, default=1024)
+    ap.add_argument("--tgt-len", dest="tgt_len", type=int, default=1024)
+    ap.add_argument("--mem-len", dest="mem_len", type=int, default=0)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--batch-chunk", type=int, default=1)
+    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from commu_amd import _lib
+    from commu_amd.ddp import GradReducer
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import Trainer, build_model
+
+    B = args.batch_per_gpu
+    cfg = get_cfg(num_layers=args.layers, num_heads=args.heads, units=args.d_model, inner_size=args.d_inner,
+                  tgt_length=args.tgt_len, mem_length=args.mem_len, batch_size=B * world,
+                  batch_chunk=args.batch_chunk, dropout=args.dropout, attention_dropout=args.dropout)
+    model = build_model(cfg, BaseVocab(), dev, seed=cfg.TRAIN.seed)
+    model.train()
+    reducer = GradReducer() if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_params(model)
+    trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer)
+    batches = [synthetic_batch(args.tgt_len, B, dev, seed=cfg.TRAIN.seed + 1000 * rank + i) for i in range(4)]
+    tokens_per_step = sum(b[3] for b in batches) // len(batches)
+
+    def run(nsteps, base):
+        for i in range(nsteps):
+            d, t, r, n = batches[(base + i) % len(batches)]
+            trainer.step(d, t, r, n)
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    prof_names = ["commu_relattn_bwd", "commu_relattn_fwd", "commu_gemm_nt_bf16", "commu_gemm_tn_bf16"]
+    _lib.profile_start(prof_names)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_stop()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = tokens_per_step * world * args.steps / elapsed
+    L, D, DI, T, M, H = args.layers, args.d_model, args.d_inner, args.tgt_len, args.mem_len, args.heads
+    f_fwd = fwd_flops_per_token(L, D, DI, T, M)
+    step_flops = 3.0 * f_fwd * tokens_per_step
+    # dominant kernel: rel-pos attention backward (dq + dk/dv kernels), algorithmic flops per launch =
+    # 2x the forward attention flops: tokens * 6*Kbar*D * 2   
+    mb_tokens = tokens_per_step // args.batch_chunk
+    kbar = M + (T + 1) / 2.0
+    attn_fwd_flops = mb_tokens * 6.0 * kbar * D
+    tot = {k: sum(v) for k, v in prof.items()}
+    cnt = {k: max(1, len(v)) for k, v in prof.items()}
+    dom = max(tot, key=tot.get)
+    flops_per_launch = {"commu_relattn_bwd": 2.0 * attn_fwd_flops, "commu_relattn_fwd": attn_fwd_flops}
+    if dom in flops_per_launch:
+        fl_launch = flops_per_launch[dom]
+    else:   # GEMMs: 2*(8D^2 + 4*D*DI)*L + 2*D*V per token fwd; fwd NT + dX NT launches, dW TN launches
+        gemm_fwd = mb_tokens * (L * (8 * D * D + 4 * D * DI) + 2 * D * 729)
+        fl_launch = (2.0 if dom == "commu_gemm_nt_bf16" else 1.0) * gemm_fwd * args.batch_chunk * args.steps / cnt[dom]
+    avg_ms = tot[dom] / cnt[dom]
+    achieved = fl_launch / (avg_ms * 1e-3) / 1e12
+    out = {
+        "metric": "training tokens/sec at d_model=512 tgt_len=1024",
+        "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"transformer-xl train step L{L} D{D} H{H} DI{DI} tgt_len{T} mem_len{M} vocab729",
+                   "global_batch": B * world, "batch_per_gpu": B, "batch_chunk": args.batch_chunk, "seq_len": T,
+                   "dropout": args.dropout, "parallelism": f"dp{world}", "optimizer": "clip1.0+Adam+invsqrt-LR",
+                   "weights": "random init (train.py:291-342)"},
+        "step_tflops_algorithmic": round(step_flops / 1e12, 3),
+        "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+        "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
+                     "time_share": {k: round(tot[k] / (1e3 * elapsed), 4) for k in tot}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,10 +91,37 @@ def load():
     return lib
 
 
+# optional per-entry-point timing with HIP events on the launching stream (bench.py roofline leg)
+_prof = None
+
+
+def profile_start(names):
+    global _prof
+    _prof = {"names": set(names), "events": {n: [] for n in names}}
+
+
+def profile_stop():
+    """Returns {name: [milliseconds per call]} (synchronises)."""
+    global _prof
+    import torch
+    torch.cuda.synchronize()
+    out = {n: [s.elapsed_time(e) for s, e in evs] for n, evs in _prof["events"].items()}
+    _prof = None
+    return out
+
+
 def call(name, *args):
     """Call an entry point and raise on a non-zero status."""
     fn = getattr(load(), name)
-    rc = fn(*args)
+    if _prof is not None and name in _prof["names"]:
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        _prof["events"][name].append((s, e))
+    else:
+        rc = fn(*args)
     if name not in _NOCHECK and rc != 0:
         raise CommuHipError(f"{name} failed with status {rc}")
     return rc

@@ -1,0 +1,132 @@
+"""Training loop of the hot path: the reference's `train()` / `evaluate()` / initialisation
+(train.py:74-110,113-169,291-342,441-461) as importable functions (the reference's train.py is a
+script with module-level CUDA/NCCL side effects and cannot be imported).
+
+Differences that do not change the arithmetic:
+ * the masked mean loss is reduced on the device (no boolean-index host sync, train.py:148);
+ * gradients of the `batch_chunk` micro-batches accumulate in the flat gradient buffer and are
+   all-reduced ONCE per optimiser step (the reference all-reduces on every micro-batch, quirk Q8;
+   the mean of sums is identical);
+ * clip + Adam are two kernels on the flat buffers.
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .functional import masked_mean
+from .model.model import MemTransformerLM
+from .optim import FusedAdam, clip_grad_norm_, lr_lambda_factory
+
+
+def weights_init(m, cfg):
+    """train.py:305-342: N(0, base_init) for Linear/Embedding weights and r_*_bias, 0 for biases,
+    N(1, base_init) for LayerNorm weights.  Dispatch on class names, as the reference does."""
+    std = cfg.INITIALIZER.base_init
+    name = m.__class__.__name__
+    if name.find("Linear") != -1:
+        if getattr(m, "weight", None) is not None:
+            nn.init.normal_(m.weight, 0.0, std)
+        if getattr(m, "bias", None) is not None:
+            nn.init.constant_(m.bias, 0.0)
+    elif name.find("AdaptiveEmbedding") != -1:
+        pass                                    # emb_projs is empty (d_proj == d_embed)
+    elif name.find("Embedding") != -1:
+        if hasattr(m, "weight"):
+            nn.init.normal_(m.weight, 0.0, std)
+    elif name.find("LayerNorm") != -1:
+        if hasattr(m, "weight"):
+            nn.init.normal_(m.weight, 1.0, std)
+        if getattr(m, "bias", None) is not None:
+            nn.init.constant_(m.bias, 0.0)
+    elif name.find("TransformerLM") != -1:
+        if hasattr(m, "r_w_bias"):
+            nn.init.normal_(m.r_w_bias, 0.0, std)
+        if hasattr(m, "r_r_bias"):
+            nn.init.normal_(m.r_r_bias, 0.0, std)
+
+
+def build_model(cfg, vocab, device, seed=None):
+    """train.py:382-438: seed, construct, weights_init, move to the device."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    model = MemTransformerLM(cfg, vocab)
+    model.apply(lambda m: weights_init(m, cfg))
+    model.word_emb.apply(lambda m: weights_init(m, cfg))
+    return model.to(device)
+
+
+class Trainer:
+    """One rank of the data-parallel training job (train.py:441-473 + train() :113-169)."""
+
+    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0):
+        self.model, self.cfg, self.num_gpus, self.reducer, self.pad_id = model, cfg, num_gpus, reducer, pad_id
+        local_lr = cfg.TRAIN.lr / num_gpus                                  # train.py:441
+        self.optimizer = FusedAdam(model, lr=local_lr, weight_decay=cfg.TRAIN.weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.LambdaLR(
+            self.optimizer, lr_lambda=lr_lambda_factory(cfg.TRAIN.warmup_step, cfg.TRAIN.lr, cfg.TRAIN.lr_min))
+        self.train_step = 0
+        self.mems: List[Optional[torch.Tensor]] = [None for _ in range(cfg.TRAIN.batch_chunk)]
+        dev = next(model.parameters()).device
+        self.log_train_loss = torch.zeros((), device=dev)
+        self.log_grad_norm = torch.zeros((), device=dev)
+        self.log_token_num = 0
+
+    def step(self, data, target, reset_mems, batch_token_num):
+        """train.py:131-169 for one batch; returns the summed micro-batch loss (device tensor)."""
+        cfg, model = self.cfg, self.model
+        chunk = cfg.TRAIN.batch_chunk
+        model.temperature = 1.0
+        model.zero_grad()
+        data_chunks = torch.chunk(data, chunk, 1)
+        target_chunks = torch.chunk(target, chunk, 1)
+        reset_chunks = torch.chunk(reset_mems, chunk, 0)
+        total = None
+        for i in range(chunk):
+            d, t, r = data_chunks[i].contiguous(), target_chunks[i].contiguous(), reset_chunks[i].contiguous()
+            loss, self.mems[i] = model(d, t, r, self.mems[i])
+            loss = masked_mean(loss, t, self.pad_id, 1.0 / chunk)
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+        if self.reducer is not None:
+            self.reducer.allreduce_mean(model)
+        grad_norm = clip_grad_norm_(model, cfg.TRAIN.clip, self.optimizer)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        self.train_step += 1
+        self.scheduler.step()
+        self.log_train_loss += total
+        self.log_grad_norm += grad_norm
+        self.log_token_num += int(batch_token_num)
+        return total
+
+    @torch.no_grad()
+    def evaluate(self, eval_iter):
+        """train.py:74-110: same_length evaluation with the longer EVALUATE memory."""
+        cfg, model = self.cfg, self.model
+        model.eval()
+        model.reset_length(tgt_len=cfg.EVALUATE.tgt_length, mem_len=cfg.EVALUATE.mem_length)
+        model.same_length = True
+        total_tok, total_nll = 0, 0.0
+        mems = None
+        for data, target, all_reset, ntok in eval_iter():
+            if all_reset:
+                mems = None
+            loss, mems = model(data, target, None, mems)
+            total_nll += ntok * float(masked_mean(loss, target, self.pad_id, 1.0))
+            total_tok += ntok
+        model.reset_length(cfg.TRAIN.tgt_length, cfg.TRAIN.mem_length)
+        model.same_length = cfg.MODEL.same_length
+        model.train()
+        return total_tok, total_nll
+
+
+def save_checkpoint(path, model, optimizer, vocab, train_step, best_val_loss, scheduler):
+    """train.py:29-54: same dictionary layout (model = unwrapped state_dict, amp = None)."""
+    torch.save({"model": {k: v.detach().float().cpu() for k, v in model.state_dict().items()},
+                "optimizer": None, "train_step": train_step, "scheduler": scheduler.state_dict(),
+                "best_val_loss": best_val_loss, "vocab": vocab, "amp": None}, path)
