@@ -61,6 +61,7 @@ PROTOTYPES = {
     "commu_attn_rdt_shift": [c_i],
     "commu_attn_delta": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "commu_sample_topk": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p}
@@ -82,6 +83,10 @@ def load():
         raise CommuHipError(
             f"{LIB_PATH} not found: build it with `python commu-code_amd/build.py` "
             "(the product path has no CPU fallback)")
+    # PyTorch ships its own libamdhip64; import it first so that this library binds to the SAME
+    # HIP runtime instance that owns torch's streams and allocations (loading ours first makes
+    # launches fail with hipErrorNoDevice).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)

@@ -325,3 +325,17 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         gemm_tn(dsk[h], qv_out[:, h * DH:(h + 1) * DH], tmp)
         drd[:, h * DH:(h + 1) * DH].copy_(tmp[:K])
     return delta
+
+
+def sample_topk(logits, temperature, top_k, wrong=None, uniforms=None, active=None, token=None, probs_out=None):
+    """In-place temperature + softmax + top-k + wrong-token mask + inverse-CDF draw per sequence.
+    logits: fp32 [nseq, >=V] (row stride = ld), modified in place (logits[:, 1:V] /= temperature)."""
+    nseq = logits.shape[0]
+    V = 729
+    assert logits.dtype == F32 and logits.stride(1) == 1
+    if token is None:
+        token = torch.empty(nseq, device=logits.device, dtype=torch.int32)
+    call("commu_sample_topk", _p(logits), logits.stride(0), nseq, V, _p(wrong), 0 if wrong is None else wrong.stride(0),
+         _p(uniforms), _p(active), float(temperature), int(top_k), _p(token), _p(probs_out),
+         0 if probs_out is None else probs_out.stride(0), _s())
+    return token

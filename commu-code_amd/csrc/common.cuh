@@ -18,6 +18,14 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 #define WAVE 64
 #define LDS_AS __attribute__((address_space(3)))
 
+// clear any stale (sticky-less) runtime error left by other users of the HIP runtime in this
+// thread, then launch; COMMU_LAUNCH_CHECK() afterwards reports only our own launch failures
+#define COMMU_LAUNCH(...)                 \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
+
 #define COMMU_LAUNCH_CHECK()                         \
     do {                                             \
         hipError_t e__ = hipGetLastError();          \

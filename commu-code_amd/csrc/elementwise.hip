@@ -407,7 +407,7 @@ extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, in
                                float scale, hipStream_t stream) {
     if (ntok <= 0) return 0;
     if (D % 4) return -22;
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, stream, tok, E, (bf16*)out,
+    COMMU_LAUNCH(embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, stream, tok, E, (bf16*)out,
                        ldo, ntok, D, scale);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -416,7 +416,7 @@ extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, in
 extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, float* dE, int ntok, int D,
                                int V, float scale, int accumulate, hipStream_t stream) {
     if (D > 1024) return -22;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, stream, tok, (const bf16*)dX, ldx, dE,
+    COMMU_LAUNCH(embed_bwd_kernel, dim3(V), dim3(256), 0, stream, tok, (const bf16*)dX, ldx, dE,
                        ntok, D, scale, accumulate);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -425,7 +425,7 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
 extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K, int D, hipStream_t stream) {
     const int n = K * (D / 2);
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_freq, (bf16*)out,
+    COMMU_LAUNCH(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_freq, (bf16*)out,
                        ld, K, D);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -436,7 +436,7 @@ extern "C" int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, c
                                    hipStream_t stream) {
     if (rows <= 0) return 0;
     if (D > 1024 || (D % 8) || (ldz % 8) || (ldy % 8)) return -22;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)z,
+    COMMU_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)z,
                        ldz, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, D, eps);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -449,7 +449,7 @@ extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int 
                                    float* part, int rows, int D, hipStream_t stream) {
     if (rows <= 0) return 0;
     if (D > 1024 || (D % 8)) return -22;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
+    COMMU_LAUNCH(layernorm_bwd_kernel, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
                        (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz,
                        part, rows, D);
     COMMU_LAUNCH_CHECK();
@@ -461,7 +461,7 @@ extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, flo
     int ny = (rows + 255) / 256;
     if (ny > 256) ny = 256;
     const int rpb = (rows + ny - 1) / ny;
-    hipLaunchKernelGGL(colsum_kernel<bf16>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream,
+    COMMU_LAUNCH(colsum_kernel<bf16>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream,
                        (const bf16*)X, ldx, rows, cols, out, rpb);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -472,7 +472,7 @@ extern "C" int commu_colsum_f32(const float* X, int ldx, int rows, int cols, flo
     int ny = (rows + 63) / 64;
     if (ny > 256) ny = 256;
     const int rpb = (rows + ny - 1) / ny;
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream, X, ldx,
+    COMMU_LAUNCH(colsum_kernel<float>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream, X, ldx,
                        rows, cols, out, rpb);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -481,7 +481,7 @@ extern "C" int commu_colsum_f32(const float* X, int ldx, int rows, int cols, flo
 extern "C" int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse,
                             int rows, int V, hipStream_t stream) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, nll,
+    COMMU_LAUNCH(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, nll,
                        lse, rows, V);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -490,7 +490,7 @@ extern "C" int commu_ce_fwd(const float* logits, int ldl, const int64_t* target,
 extern "C" int commu_ce_bwd(const float* logits, int ldl, const int64_t* target, const float* lse,
                             const float* g, void* dlogits, int ldd, int rows, int V, hipStream_t stream) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, lse,
+    COMMU_LAUNCH(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, lse,
                        g, (bf16*)dlogits, ldd, rows, V);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -499,8 +499,8 @@ extern "C" int commu_ce_bwd(const float* logits, int ldl, const int64_t* target,
 extern "C" int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out,
                                hipStream_t stream) {
     if (npart <= 0 || npart > 1024) return -22;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(npart), dim3(256), 0, stream, g, n, part);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, part, npart, out);
+    COMMU_LAUNCH(sumsq_partial_kernel, dim3(npart), dim3(256), 0, stream, g, n, part);
+    COMMU_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, part, npart, out);
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -510,7 +510,7 @@ extern "C" int commu_adam_step(float* p, const float* g, float* m, float* v, voi
                                const float* gnorm, float clip, hipStream_t stream) {
     if (n == 0) return 0;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
+    COMMU_LAUNCH(adam_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
                        (bf16*)p_bf16, n, lr, beta1, beta2, eps, bc1, bc2, gnorm, clip);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -518,7 +518,7 @@ extern "C" int commu_adam_step(float* p, const float* g, float* m, float* v, voi
 
 extern "C" int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, float clip, hipStream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(scale_clip_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, g, n, gnorm,
+    COMMU_LAUNCH(scale_clip_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, g, n, gnorm,
                        clip);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -526,7 +526,7 @@ extern "C" int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, floa
 
 extern "C" int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, in,
+    COMMU_LAUNCH(cast_f32_bf16_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, in,
                        (bf16*)out, n);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -534,7 +534,7 @@ extern "C" int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStre
 
 extern "C" int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream,
+    COMMU_LAUNCH(cast_bf16_f32_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream,
                        (const bf16*)in, out, n);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -543,7 +543,7 @@ extern "C" int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStre
 extern "C" int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, int cols,
                                     hipStream_t stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream,
+    COMMU_LAUNCH(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, stream,
                        (const bf16*)in, ldi, (bf16*)out, ldo, rows, cols);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -552,7 +552,7 @@ extern "C" int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo,
 extern "C" int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
                                         hipStream_t stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(transpose_f32_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
+    COMMU_LAUNCH(transpose_f32_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0,
                        stream, in, ldi, (bf16*)out, ldo, rows, cols);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -564,9 +564,9 @@ extern "C" int commu_masked_mean(const float* nll, const int64_t* target, int n,
     hipMemsetAsync(sum_ws, 0, sizeof(float), stream);
     hipMemsetAsync(cnt_ws, 0, sizeof(int), stream);
     if (n > 0)
-        hipLaunchKernelGGL(masked_sum_kernel, dim3(cap_blocks((n + 1023) / 1024)), dim3(256), 0, stream, nll,
+        COMMU_LAUNCH(masked_sum_kernel, dim3(cap_blocks((n + 1023) / 1024)), dim3(256), 0, stream, nll,
                            target, n, pad, sum_ws, cnt_ws);
-    hipLaunchKernelGGL(masked_mean_final_kernel, dim3(1), dim3(1), 0, stream, sum_ws, cnt_ws, scale, out);
+    COMMU_LAUNCH(masked_mean_final_kernel, dim3(1), dim3(1), 0, stream, sum_ws, cnt_ws, scale, out);
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -575,7 +575,7 @@ extern "C" int commu_loss_grad(const int64_t* target, int n, int pad, const int*
                                float* g, hipStream_t stream) {
     // g[m] = scale * (target[m] != pad) / cnt_ws[0]   (cnt_ws filled by commu_masked_mean)
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(loss_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, target, n, pad, cnt_ws,
+    COMMU_LAUNCH(loss_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, target, n, pad, cnt_ws,
                        scale, g);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -584,7 +584,7 @@ extern "C" int commu_loss_grad(const int64_t* target, int n, int pad, const int*
 extern "C" int commu_copy_bf16(const void* src, void* dst, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
     if (n % 8) return -22;
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(cap_blocks((n / 8 + 255) / 256)), dim3(256), 0, stream,
+    COMMU_LAUNCH(copy_rows_kernel, dim3(cap_blocks((n / 8 + 255) / 256)), dim3(256), 0, stream,
                        (const bf16*)src, (bf16*)dst, n / 8);
     COMMU_LAUNCH_CHECK();
     return 0;

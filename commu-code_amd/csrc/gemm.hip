@@ -317,11 +317,11 @@ extern "C" int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n);
     if (flags & COMMU_EPI_OUT_F32)
-        hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
+        COMMU_LAUNCH(gemm_nt_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
                            (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
                            (const bf16*)relu_mask, ldm, flags, tiles_n);
     else
-        hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
+        COMMU_LAUNCH(gemm_nt_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
                            (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
                            (const bf16*)relu_mask, ldm, flags, tiles_n);
     COMMU_LAUNCH_CHECK();
@@ -338,7 +338,7 @@ extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb
     const bool narrow = (K <= 64);
     dim3 grid((N + 127) / 128, narrow ? (K + 63) / 64 : (K + 127) / 128, nslices);
 #define TN_LAUNCH(NC, MD)                                                                          \
-    hipLaunchKernelGGL((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,  \
+    COMMU_LAUNCH((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,  \
                        (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps)
     if (narrow) {
         if (mode) TN_LAUNCH(64, 1); else TN_LAUNCH(64, 0);
@@ -356,7 +356,7 @@ extern "C" int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, in
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n,
+    COMMU_LAUNCH(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n,
                        nslabs, stride, accumulate);
     COMMU_LAUNCH_CHECK();
     return 0;

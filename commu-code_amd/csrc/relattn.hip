@@ -633,8 +633,8 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, const void* vt, int J
     fill_common(a, d);
     a.vt = (const bf16*)vt; a.Jpad = Jpad; a.out = (bf16*)out; a.lse = lse;
     dim3 grid((d->T + 63) / 64, d->H, d->B);
-    if (d->DH == 64) hipLaunchKernelGGL(relattn_fwd_kernel<64>, grid, dim3(256), 0, stream, a);
-    else if (d->DH == 32) hipLaunchKernelGGL(relattn_fwd_kernel<32>, grid, dim3(256), 0, stream, a);
+    if (d->DH == 64) COMMU_LAUNCH(relattn_fwd_kernel<64>, grid, dim3(256), 0, stream, a);
+    else if (d->DH == 32) COMMU_LAUNCH(relattn_fwd_kernel<32>, grid, dim3(256), 0, stream, a);
     else return -22;
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -656,11 +656,11 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     a.sft = (8 - ((d->M + 1) % 8)) % 8;
     dim3 gq((d->T + 63) / 64, d->H, d->B), gk((K + 63) / 64, d->H, d->B);
     if (d->DH == 64) {
-        hipLaunchKernelGGL(relattn_bwd_q_kernel<64>, gq, dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(relattn_bwd_kv_kernel<64>, gk, dim3(256), 0, stream, a);
+        COMMU_LAUNCH(relattn_bwd_q_kernel<64>, gq, dim3(256), 0, stream, a);
+        COMMU_LAUNCH(relattn_bwd_kv_kernel<64>, gk, dim3(256), 0, stream, a);
     } else if (d->DH == 32) {
-        hipLaunchKernelGGL(relattn_bwd_q_kernel<32>, gq, dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(relattn_bwd_kv_kernel<32>, gk, dim3(256), 0, stream, a);
+        COMMU_LAUNCH(relattn_bwd_q_kernel<32>, gq, dim3(256), 0, stream, a);
+        COMMU_LAUNCH(relattn_bwd_kv_kernel<32>, gk, dim3(256), 0, stream, a);
     } else return -22;
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -672,7 +672,7 @@ extern "C" int commu_attn_delta(const void* o, const void* dout, int ld, float* 
                                 int DH, hipStream_t stream) {
     if (T * B <= 0) return 0;
     if ((DH != 32 && DH != 64 && DH != 128) || (ld % 8)) return -22;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((T * B + 3) / 4), dim3(256), 0, stream, (const bf16*)o,
+    COMMU_LAUNCH(attn_delta_kernel, dim3((T * B + 3) / 4), dim3(256), 0, stream, (const bf16*)o,
                        (const bf16*)dout, ld, delta, T, B, H, DH);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -681,7 +681,7 @@ extern "C" int commu_attn_delta(const void* o, const void* dout, int ld, float* 
 extern "C" int commu_transpose_heads(const void* src, int ld, const float* bias, void* dst, int J, int B, int H,
                                      int DH, int W, int off, hipStream_t stream) {
     if (B * H <= 0 || W <= 0) return 0;
-    hipLaunchKernelGGL(transpose_heads_kernel, dim3((W + 63) / 64, B * H), dim3(256), 0, stream,
+    COMMU_LAUNCH(transpose_heads_kernel, dim3((W + 63) / 64, B * H), dim3(256), 0, stream,
                        (const bf16*)src, ld, bias, (bf16*)dst, J, B, H, DH, W, off);
     COMMU_LAUNCH_CHECK();
     return 0;

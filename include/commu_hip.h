@@ -138,6 +138,17 @@ int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int 
 int commu_transpose_heads(const void* src, int ld, const float* bias, void* dst, int J, int B, int H,
                           int DH, int W, int off, hipStream_t stream);
 
+/* ---- sampling step of the decode loop (InferenceTask.calc_probs / apply_sampling / infer_token,
+ * commu/midi_generator/midi_inferrer.py:209-237), one wave per sequence:
+ *   logits[b][1:V] /= temperature IN PLACE (quirk Q5), softmax, pad column 0 -> 0 (Q6), keep the
+ *   top_k, zero wrong[b][id] != 0, renormalise, draw by inverse CDF with uniforms[b].
+ *   temperature == 0: one-hot argmax.  token[b] = -1 when nothing can be drawn (Q12).
+ *   active (optional): only sequences with active[b] != 0 are processed.
+ *   probs_out (optional): the [nseq][ldp] distribution that was drawn from. */
+int commu_sample_topk(float* logits, int ld, int nseq, int V, const unsigned char* wrong, int ldw,
+                      const float* uniforms, const unsigned char* active, float temperature, int top_k,
+                      int* token, float* probs_out, int ldp, hipStream_t stream);
+
 /* library identification */
 const char* commu_hip_version(void);
 
