@@ -40,7 +40,10 @@ def cpu_baseline(args):
     golden fixtures) timed on the host cores: same shape, micro-batch 2 (CPU tokens/s is roughly
     batch independent), 1 warm-up + timed steps bounded to ~20 s."""
     from oracle import xl_ref as X
-    torch.set_num_threads(os.cpu_count())
+    # 16 threads is the fastest setting for this step on the MI355X host (8: 1.7 s, 16: 1.4 s, 32: 1.4 s,
+    # 64: 2.5 s, 256: 157 s per step -- measured with tests/probes/cpu_threads.py)
+    nthreads = min(os.cpu_count(), 16)
+    torch.set_num_threads(nthreads)
     s = X.XLShape(args.layers, args.heads, args.d_model, args.d_inner)
     p = X.init_params(s, 1)
     st = X.adam_init(p)
@@ -59,7 +62,7 @@ def cpu_baseline(args):
         if time.time() - t_start > 25 and times:
             break
     per = sum(times) / len(times)
-    return {"value": round(Bc * T / per, 1), "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(Bc * T / per, 1), "unit": "tokens/s", "cores": nthreads, "kind": "port",
             "sample": f"{len(times)} optimiser steps of the same model shape at batch {Bc} x tgt_len {T} "
                       f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step)"}
 
