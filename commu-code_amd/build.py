@@ -16,6 +16,8 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libcommu_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+         # keep MFMA accumulators in VGPRs (gfx950 has a unified file): no v_accvgpr_* copies around the VALU work
+         "-mllvm", "-amdgpu-mfma-vgpr-form",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

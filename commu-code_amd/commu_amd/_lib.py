@@ -25,17 +25,15 @@ class AttnDesc(C.Structure):
 
 
 class AttnBwdDesc(C.Structure):
-    _fields_ = [("o", c_p), ("dout", c_p), ("lse", c_p), ("delta", c_p), ("kt", c_p), ("rdt", c_p),
-                ("qut", c_p), ("dot", c_p), ("dq", c_p), ("dk", c_p), ("dv", c_p), ("qv_out", c_p),
-                ("dsk", c_p), ("du_part", c_p), ("dvb_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
-                ("Jpad", c_i), ("Tpad", c_i), ("Wr", c_i)]
+    _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
+                ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
 PROTOTYPES = {
     "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
-    "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_p],
+    "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
     "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
     "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, c_p],
@@ -56,16 +54,15 @@ PROTOTYPES = {
     "commu_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_transpose_f32_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_copy_bf16": [c_p, c_p, c_z, c_p],
-    "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_i, c_p, c_p, c_p],
+    "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p],
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
-    "commu_attn_rdt_shift": [c_i],
     "commu_attn_delta": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_sample_topk": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_attn_rdt_shift", "commu_hip_version"}
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version"}
 
 _lib = None
 

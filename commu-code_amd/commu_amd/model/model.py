@@ -108,7 +108,7 @@ class RelPartialLearnableDecoderLayer(nn.Module):
 
 class _Saved:
     """Activations of one forward call kept for its backward."""
-    __slots__ = ("T", "M", "B", "tokens", "target", "reset", "h", "cat", "qkv", "rd", "vec", "lse", "z1", "mu1",
+    __slots__ = ("T", "M", "B", "tokens", "target", "reset", "h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1",
                  "rs1", "a", "hid", "z2", "mu2", "rs2", "pd", "hL", "logits", "ce_lse", "same_length", "mem_len")
 
 
@@ -324,7 +324,7 @@ class MemTransformerLM(nn.Module):
         if need_grad:
             sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
             sv.same_length, sv.mem_len = bool(self.same_length), int(self.mem_len)
-            for k in ("h", "cat", "qkv", "rd", "vec", "lse", "z1", "mu1", "rs1", "a", "hid", "z2", "mu2", "rs2"):
+            for k in ("h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1", "rs1", "a", "hid", "z2", "mu2", "rs2"):
                 setattr(sv, k, [])
         u, vb = self.r_w_bias, self.r_r_bias
         for i in range(L):
@@ -338,8 +338,9 @@ class MemTransformerLM(nn.Module):
                 ops.gemm_nt(cat, w["qkv"][HD:], out=qkv[:M * B, HD:])
             ops.gemm_nt(h, w["qkv"], out=qkv[M * B:])
             rd = ops.gemm_nt(pd, w["r"])                                         # K5
-            vec, lse, _ = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
-                                          T, M, B, H, DH, bool(self.same_length), int(self.mem_len))   # K6
+            vec, lse, qs = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
+                                           T, M, B, H, DH, bool(self.same_length), int(self.mem_len),
+                                           save_q=need_grad)                                   # K6
             z1 = ops.gemm_nt(vec, w["o"], resid=h)                               # K7
             a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)
             hid = ops.gemm_nt(a, w["w1"], bias=lay[i].pos_ff.CoreNet[0].bias, relu=True)     # K8
@@ -347,7 +348,7 @@ class MemTransformerLM(nn.Module):
             y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias)
             if need_grad:
                 sv.h.append(h); sv.cat.append(cat); sv.qkv.append(qkv); sv.rd.append(rd); sv.vec.append(vec)
-                sv.lse.append(lse); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1); sv.a.append(a)
+                sv.lse.append(lse); sv.qs.append(qs); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1); sv.a.append(a)
                 sv.hid.append(hid); sv.z2.append(z2); sv.mu2.append(mu2); sv.rs2.append(rs2)
             h = y
             hids.append(h)
@@ -443,7 +444,7 @@ class MemTransformerLM(nn.Module):
             drd = torch.empty(K, HD, device=dev, dtype=F32)
             ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], self.r_w_bias,
                             self.r_r_bias, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
-                            sv.lse[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb)
+                            sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb)
             self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HD, D)))
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HD, D))
             self._tn_acc(dqkv[M * B:], sv.h[i], gW)
@@ -467,4 +468,4 @@ class MemTransformerLM(nn.Module):
             fl["slabs"] = torch.empty(need, device=fl["dev"], dtype=F32)
         ops.gemm_tn_raw(dY, Xa, fl["slabs"], ns)
         nrows = N if rows is None else rows
-        ops.reduce_slabs(gW, fl["slabs"], nrows * Kc, ns, N * Kc, True)
+        ops.reduce_slabs(gW, fl["slabs"], nrows * Kc, ns, N * Kc, True, 1.0)

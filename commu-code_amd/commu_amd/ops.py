@@ -88,7 +88,7 @@ def gemm_tn(A, B, out, *, accumulate=False, slabs=None, mode=None):
         slabs = torch.empty(ns * N * K, device=A.device, dtype=F32)
     call("commu_gemm_tn_bf16", _p(A), lda, _p(B), ldb, _p(slabs), K, N * K, M, N, K, ns,
          TN_MODE if mode is None else mode, _s())
-    call("commu_reduce_slabs_f32", _p(out), _p(slabs), N * K, ns, N * K, 1 if accumulate else 0, _s())
+    call("commu_reduce_slabs_f32", _p(out), _p(slabs), N * K, ns, N * K, 1 if accumulate else 0, 1.0, _s())
     return out
 
 
@@ -103,10 +103,10 @@ def gemm_tn_raw(A, B, slabs, nslices, mode=None):
     return slabs
 
 
-def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate):
-    """dst.view(-1)[:n] (+)= sum_s slabs[s*stride : s*stride + n]"""
+def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate, alpha=1.0):
+    """dst.view(-1)[:n] = (accumulate ? dst : 0) + alpha * sum_s slabs[s*stride : s*stride + n]"""
     assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() >= n
-    call("commu_reduce_slabs_f32", _p(dst), _p(slabs), n, nslabs, stride, 1 if accumulate else 0, _s())
+    call("commu_reduce_slabs_f32", _p(dst), _p(slabs), n, nslabs, stride, 1 if accumulate else 0, float(alpha), _s())
     return dst
 
 
@@ -256,74 +256,65 @@ def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem
     return d
 
 
-class AttnWorkspace:
-    """Buffers of one attention call (sizes depend on T, M, B, H, DH only)."""
-
-    def __init__(self, T, M, B, H, DH, device):
-        K = T + M
-        self.T, self.M, self.B, self.H, self.DH, self.K = T, M, B, H, DH, K
-        self.Jpad = round_up(K, 64)
-        self.Tpad = round_up(T, 64)
-        self.Wr = round_up(128 + 8 + K + 192, 8)
-        self.QT = (T + 63) // 64
-        self.device = device
-
-
-def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None, vt=None):
+def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None,
+                save_q=False):
     """q: 2-D view [T*B, H*DH] (row stride ld_qkv), k, v: [(T+M)*B, H*DH]; rd: [K, H*DH] by distance.
-    Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], vt)."""
-    K = T + M
-    Jpad = round_up(K, 64)
-    if vt is None:
-        vt = torch.empty(B, H, DH, Jpad, device=q.device, dtype=BF16)
-    transpose_heads(v, K, B, H, DH, Jpad, 0, None, vt)
+    Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], (qu2, qv2) or None)."""
     if out is None:
         out = torch.empty(T * B, H * DH, device=q.device, dtype=BF16)
     if lse is None:
         lse = torch.empty(B, H, T, device=q.device, dtype=F32)
+    qs = None
+    if save_q:
+        qs = (torch.empty(T * B, H * DH, device=q.device, dtype=BF16), torch.empty(T * B, H * DH, device=q.device, dtype=BF16))
     d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len)
-    call("commu_relattn_fwd", C.byref(d), _p(vt), Jpad, _p(out), _p(lse), _s())
-    return out, lse, vt
+    call("commu_relattn_fwd", C.byref(d), _p(out), _p(lse), _p(qs[0]) if qs else None, _p(qs[1]) if qs else None, _s())
+    return out, lse, qs
 
 
-def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, dq, dk, dv,
+def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
                 drd, du, dvb):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
     drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
     dev = q.device
     K = T + M
-    Jpad, Tpad = round_up(K, 64), round_up(T, 64)
-    Wr = round_up(128 + 8 + K + 192, 8)
+    HD = H * DH
     QT = (T + 63) // 64
-    sft = call("commu_attn_rdt_shift", M)
+    qu2, qv2 = qs
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
     call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
-    kt = transpose_heads(k, K, B, H, DH, Jpad)
-    qut = transpose_heads(q, T, B, H, DH, Tpad, 0, u)
-    dot = transpose_heads(dout, T, B, H, DH, Tpad)
-    rdt = transpose_heads(rd, K, 1, H, DH, Wr, 128 + sft)
-    qv_out = torch.empty(T * B, H * DH, device=dev, dtype=BF16)
-    ld_dsk = round_up(K, 8)
+    ld_dsk = round_up(K, 32)
     dsk = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
-    du_part = torch.empty(B * QT, H * DH, device=dev, dtype=F32)
-    dvb_part = torch.empty(B * QT, H * DH, device=dev, dtype=F32)
+    dq_ac = torch.empty(T * B, HD, device=dev, dtype=BF16)
+    du_part = torch.empty(B * QT, HD, device=dev, dtype=F32)
     d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len)
     e = AttnBwdDesc()
-    e.o, e.dout, e.lse, e.delta = o.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
-    e.kt, e.rdt, e.qut, e.dot = kt.data_ptr(), rdt.data_ptr(), qut.data_ptr(), dot.data_ptr()
-    e.dq, e.dk, e.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
-    e.qv_out, e.dsk = qv_out.data_ptr(), dsk.data_ptr()
-    e.du_part, e.dvb_part = du_part.data_ptr(), dvb_part.data_ptr()
-    e.ld_dqkv, e.ld_dsk, e.Jpad, e.Tpad, e.Wr = dq.stride(0), ld_dsk, Jpad, Tpad, Wr
-    assert dk.stride(0) == dq.stride(0) and dv.stride(0) == dq.stride(0)
+    e.dout, e.lse, e.delta = dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    e.qu2, e.qv2 = qu2.data_ptr(), qv2.data_ptr()
+    e.dq_ac, e.dk, e.dv = dq_ac.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    e.dsk, e.du_part = dsk.data_ptr(), du_part.data_ptr()
+    e.ld_dqkv, e.ld_dsk = dk.stride(0), ld_dsk
+    assert dv.stride(0) == dk.stride(0)
     call("commu_relattn_bwd", C.byref(d), C.byref(e), _s())
-    colsum(du_part, du)
-    colsum(dvb_part, dvb)
-    # dRd[d, h*DH+f] = sum_m dSk[h][m][d] * (q+v)[m][h*DH+f]
-    tmp = torch.empty(ld_dsk, DH, device=dev, dtype=F32)      # pad columns of dsk are zero
+    # BD part of dq and dRd: two GEMMs per head over dS-by-distance
+    rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
+    c2 = d.scale * 1.4426950408889634
+    ns = tn_slices(T * B, ld_dsk, DH)
+    slabs = torch.empty(ns * ld_dsk * DH, device=dev, dtype=F32)
+    tmp = torch.empty(ld_dsk, DH, device=dev, dtype=F32)
     for h in range(H):
-        gemm_tn(dsk[h], qv_out[:, h * DH:(h + 1) * DH], tmp)
-        drd[:, h * DH:(h + 1) * DH].copy_(tmp[:K])
+        sl = slice(h * DH, (h + 1) * DH)
+        gemm_nt(dsk[h], rdt[0, h], out=dq[:, sl], resid=dq_ac[:, sl])
+        gemm_tn_raw(dsk[h], qv2[:, sl], slabs, ns)
+        reduce_slabs(tmp, slabs, ld_dsk * DH, ns, ld_dsk * DH, False, 1.0 / c2)
+        drd[:, sl].copy_(tmp[:K])
+    # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)
+    ca = torch.zeros(HD, device=dev, dtype=F32)
+    colsum(du_part, ca)
+    ct = torch.zeros(HD, device=dev, dtype=F32)
+    colsum(dq, ct)
+    du.add_(ca)
+    dvb.add_(ct - ca)
     return delta
 
 

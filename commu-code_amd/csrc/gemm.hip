@@ -285,21 +285,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     }
 }
 
-// dst[i] (+)= sum_s src[s*stride + i]
+// dst[i] = (accumulate ? dst[i] : 0) + alpha * sum_s src[s*stride + i]
 __global__ void reduce_slabs_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n,
-                                    int nslabs, size_t stride, int accumulate) {
+                                    int nslabs, size_t stride, int accumulate, float alpha) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t step = (size_t)gridDim.x * blockDim.x * 4;
     for (; i < n; i += step) {
         if (i + 3 < n) {
             f32x4 s = *(const f32x4*)(src + i);
             for (int k = 1; k < nslabs; ++k) s += *(const f32x4*)(src + (size_t)k * stride + i);
+            s *= alpha;
             if (accumulate) s += *(const f32x4*)(dst + i);
             *(f32x4*)(dst + i) = s;
         } else {
             for (size_t j = i; j < n; ++j) {
                 float s = src[j];
                 for (int k = 1; k < nslabs; ++k) s += src[(size_t)k * stride + j];
+                s *= alpha;
                 if (accumulate) s += dst[j];
                 dst[j] = s;
             }
@@ -351,13 +353,13 @@ extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb
 }
 
 extern "C" int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs,
-                                      size_t stride, int accumulate, hipStream_t stream) {
+                                      size_t stride, int accumulate, float alpha, hipStream_t stream) {
     if (n == 0) return 0;
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     COMMU_LAUNCH(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n,
-                       nslabs, stride, accumulate);
+                       nslabs, stride, accumulate, alpha);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

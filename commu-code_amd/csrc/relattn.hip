@@ -11,49 +11,51 @@
 // source lane differs only in its low 4 bits) + a select between two adjacent 16-wide blocks.
 //
 // Layout: activations are time-major rows m = t*B + b (as the reference), so row j of a
-// (b,h) matrix is `base + (j*B + b)*ld + h*DH`.  Operands whose contraction index is the ROW
-// index (V in P.V, K in dS.K, Rd in dQR.Rd, Q/dO in the dK/dV products) are read from
-// pre-transposed copies [b][h][f][j] made by commu_transpose_heads, so every LDS image is a
-// plain row-major tile with an XOR swizzle and every fragment is one 16-byte (or 8-byte) read.
+// (b,h) matrix is `base + (j*B + b)*ld + h*DH`.  All LDS tiles are row-major copies of global
+// tiles ([row][feature], XOR-swizzled 16-byte chunks); an MFMA operand whose contraction index
+// is the tile's ROW index (V in P.V, K in dS.K, dO / Q in the dV / dK products) is fetched with
+// ds_read_b64_tr_b16 transpose reads, so no transposed copies exist in HBM.
 //
-// Kernels: relattn_fwd (q-stationary), relattn_bwd_q (q-stationary: dq, du/dv partials, the
-// skewed dS band for dR), relattn_bwd_kv (kv-stationary: dk, dv), attn_delta, transpose_heads.
+// Scores live in the log2 domain: q+u and q+v are pre-multiplied by scale*log2(e) when their MFMA
+// fragments are built (forward writes them out as qu2 / qv2 for the backward kernels).
+//
+// Kernels: relattn_fwd (q-stationary), relattn_bwd_q (q-stationary: the AC part of dq, its column
+// sums, and dS indexed by distance for the dR / dq_BD GEMMs), relattn_bwd_kv (kv-stationary: dk,
+// dv), attn_delta, transpose_heads.
 #include "common.cuh"
 #include "commu_hip.h"
 
 namespace {
 
 struct AttnArgs {
-    const bf16* q;      // rows i in [0,T)   : q  + (i*B+b)*ld_qkv + h*DH
+    const bf16* q;      // rows i in [0,T)   : q  + (i*B+b)*ld_qkv + h*DH        (forward only)
     const bf16* k;      // rows j in [0,K)   : k  + (j*B+b)*ld_qkv + h*DH
     const bf16* v;
-    const bf16* kt;     // [B][H][DH][Jpad]  (bwd_q)
-    const bf16* vt;     // [B][H][DH][Jpad]  (fwd)
-    const bf16* rd;     // [K][H*DH] distance-indexed
-    const bf16* rdt;    // [H][DH][Wr], entry [f][128 + sft + d] = Rd[d][f]   (bwd_q)
-    const bf16* qut;    // [B][H][DH][Tpad]  (q+u)^T  (bwd_kv)
-    const bf16* dot;    // [B][H][DH][Tpad]  dO^T     (bwd_kv)
+    const bf16* rd;     // [K][ld_rd] distance-indexed, + h*DH
     const float* u;     // r_w_bias [H][DH]
     const float* vb;    // r_r_bias [H][DH]
     const unsigned char* reset;   // [B] or null
-    const bf16* o;      // forward output (bwd)
-    const bf16* dout;   // dO rows like q, ld_o
+    bf16* qu2;          // [T*B][H*DH] (q+u)*scale*log2e : written by fwd (may be null), read by bwd
+    bf16* qv2;
+    const bf16* dout;   // dO rows like out, ld_o
     const float* lse_in;
     const float* delta;
     bf16* out;          // [T*B][ld_o]
     float* lse;         // [B][H][T]
-    bf16* dq;           // rows like q, ld_dqkv
-    bf16* dk;
+    bf16* dq;           // [T*B][H*DH] AC part of dq
+    bf16* dk;           // rows like k, ld_dqkv
     bf16* dv;
-    bf16* qv_out;       // [T*B][H*DH]  (q+v), for the dR GEMM
-    bf16* dsk;          // [H][T*B][ld_dsk]  skewed dS (index d), for the dR GEMM
-    float* du_part;     // [B*QT][H*DH]
-    float* dvb_part;
+    bf16* dsk;          // [H][T*B][ld_dsk]  dS indexed by distance d (zero-initialised by the caller)
+    float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
-    int T, M, B, H, Jpad, Tpad, Wr, sft;
+    int T, M, B, H;
     int same_length, sshift;
     float scale;
 };
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int PT = 20;      // pitch (elements) of a per-wave transposed tile [64 kv][16 rows]
 
 template <int COLS>
 __device__ __forceinline__ int swz(int row) {
@@ -62,59 +64,48 @@ __device__ __forceinline__ int swz(int row) {
     if (CH == 8) return row & 7;
     return ((row >> 3) & 1) * 3;      // 64-byte rows (see gemm.hip swz64)
 }
-
-// stage ROWS x COLS (bf16) into a swizzled row-major LDS tile; row r comes from
-// src + r*rstride; rows outside [vlo, vhi) are zero-filled.
-template <int ROWS, int COLS>
-__device__ __forceinline__ void stage(bf16* dst, const bf16* src, size_t rstride, int vlo, int vhi, int tid) {
-    constexpr int CH = COLS / 8;
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = tid; i < ROWS * CH; i += 256) {
-        const int r = i / CH, c = i % CH;
-        bf16x8 v = z;
-        if (r >= vlo && r < vhi) v = ld_bf16x8(src + (ptrdiff_t)r * (ptrdiff_t)rstride + c * 8);
-        st_bf16x8(dst + r * COLS + ((c ^ (swz<COLS>(r) & (CH - 1))) << 3), v);
-    }
-}
-// same, adding a per-column fp32 bias (q + u / q + v)
-template <int ROWS, int COLS>
-__device__ __forceinline__ void stage_bias(bf16* dst, const bf16* src, size_t rstride, int vlo, int vhi,
-                                           const float* bias, int tid) {
-    constexpr int CH = COLS / 8;
-#pragma unroll
-    for (int i = tid; i < ROWS * CH; i += 256) {
-        const int r = i / CH, c = i % CH;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (r >= vlo && r < vhi) {
-            bf16x8 raw = ld_bf16x8(src + (ptrdiff_t)r * (ptrdiff_t)rstride + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(raw[e]) + bias[c * 8 + e]);
-        }
-        st_bf16x8(dst + r * COLS + ((c ^ (swz<COLS>(r) & (CH - 1))) << 3), v);
-    }
-}
 template <int COLS>
 __device__ __forceinline__ bf16x8 frag(const bf16* tile, int row, int chunk) {
     constexpr int CH = COLS / 8;
     return ld_bf16x8(tile + row * COLS + ((chunk ^ (swz<COLS>(row) & (CH - 1))) << 3));
 }
-// 4 consecutive elements starting at column col (col % 4 == 0)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x4 tr_read(const bf16* p) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)p));
+}
+// MFMA operand whose 8 k-slots are ROWS row0..row0+3, row1..row1+3 of a row-major swizzled tile and
+// whose 16 rows/cols are the tile COLUMNS col0..col0+15: two transpose reads (lane i of a 16-lane
+// group supplies the address of 4 consecutive columns of row (i>>2)).
 template <int COLS>
-__device__ __forceinline__ bf16x4 frag4(const bf16* tile, int row, int col) {
+__device__ __forceinline__ bf16x8 frag_tr_rm(const bf16* tile, int row0, int row1, int col0, int r16) {
     constexpr int CH = COLS / 8;
-    const int chunk = col >> 3;
-    return *(const bf16x4*)(tile + row * COLS + ((chunk ^ (swz<COLS>(row) & (CH - 1))) << 3) + (col & 7));
+    bf16x8 f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (h ? row1 : row0) + (r16 >> 2);
+        const int col = col0 + 4 * (r16 & 3);
+        const bf16x4 v = tr_read(tile + row * COLS + (((col >> 3) ^ (swz<COLS>(row) & (CH - 1))) << 3) + (col & 7));
+        f[4 * h + 0] = v[0]; f[4 * h + 1] = v[1]; f[4 * h + 2] = v[2]; f[4 * h + 3] = v[3];
+    }
+    return f;
+}
+// A operand (16 rows x 32 k) from a per-wave transposed image T[k][row] (pitch PT)
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* img, int kbase, int r16, int g) {
+    bf16x8 f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bf16x4 v = tr_read(img + (kbase + 8 * g + 4 * h + (r16 >> 2)) * PT + 4 * (r16 & 3));
+        f[4 * h + 0] = v[0]; f[4 * h + 1] = v[1]; f[4 * h + 2] = v[2]; f[4 * h + 3] = v[3];
+    }
+    return f;
 }
 
 __device__ __forceinline__ float bperm(int addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
-
 __device__ __forceinline__ bool is_masked(int i, int j, int M, int same_length, int sshift, bool rst) {
     return (j > i + M) || (same_length && j <= i - sshift) || (rst && j < M);
 }
-
 // kv tile range visible from query rows [i0, i0+63]
 __device__ __forceinline__ void kv_range(const AttnArgs& a, int i0, bool rst, int& jt_lo, int& jt_hi) {
     const int K = a.T + a.M;
@@ -126,27 +117,68 @@ __device__ __forceinline__ void kv_range(const AttnArgs& a, int i0, bool rst, in
     jt_hi = jhi >> 6;
 }
 
-constexpr int PP = 72;    // pitch of the per-wave P tile [16][64] (+8 pad: 144-byte rows)
-constexpr int PP2 = 104;  // pitch of the per-wave dQR tile [16][96] (+8)
+// ---------------------------------------------------------------------------------------------
+// Tile staging through registers with buffer loads: one SRD per operand, a per-thread byte offset
+// computed once, one v_add per load per tile; rows outside the tensor (kv rows >= K, band distances
+// d < 0 or d >= K) are outside the SRD's range and read as zero in hardware -- no clamps, no
+// branches.  Loads for tile t+1 are issued before tile t is computed and committed to LDS after it.
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_ld(srd_t r, unsigned byte_off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+template <int ROWS, int COLS>
+struct Stager {
+    static constexpr int CH = COLS / 8;
+    static constexpr int N = (ROWS * CH) / 256;
+    static_assert((ROWS * CH) % 256 == 0, "tile must be a multiple of 256 16-byte chunks");
+    bf16x8 reg[N];
+    unsigned goff[N];      // byte offset of this thread's chunk n inside the tile (global side)
+    unsigned loff[N];      // swizzled byte offset inside the LDS tile
+    __device__ __forceinline__ void init(unsigned row_stride_bytes, int tid) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const int i = tid + 256 * n, r = i / CH, c = i % CH;
+            goff[n] = (unsigned)r * row_stride_bytes + (unsigned)c * 16u;
+            loff[n] = (unsigned)(r * COLS + ((c ^ (swz<COLS>(r) & (CH - 1))) << 3)) * 2u;
+        }
+    }
+    __device__ __forceinline__ void load(srd_t srd, unsigned tile_off) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) reg[n] = buf_ld(srd, goff[n] + tile_off);
+    }
+    __device__ __forceinline__ void store(bf16* dst) const {
+#pragma unroll
+        for (int n = 0; n < N; ++n) *(bf16x8*)((char*)dst + loff[n]) = reg[n];
+    }
+};
+
+// band row x (0..127) of tile number t lives in a ring of two 64-row halves: half (x>>6) of tile t
+// sits at physical half ((x>>6) + t) & 1, so the half shared by consecutive tiles is never moved.
+__device__ __forceinline__ int ring_row(int x, int t) { return ((((x >> 6) + t) & 1) << 6) + (x & 63); }
 
 // =============================================================================================
 template <int DH>
 __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     __shared__ __attribute__((aligned(16))) bf16 sK[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sVt[DH * 64];
+    __shared__ __attribute__((aligned(16))) bf16 sV[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sR[128 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sP[4 * 16 * PP];
+    __shared__ __attribute__((aligned(16))) bf16 sP[4 * 64 * PT];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int i0 = qt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const size_t rs = (size_t)B * a.ld_qkv;
+    const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;           // bytes between consecutive kv rows
+    const float c2 = a.scale * LOG2E;
 
     bf16x8 qu[KS], qv[KS];
     {
-        const int iq = min(i0 + 16 * w + r16, T - 1);
+        const int irow = i0 + 16 * w + r16;
+        const int iq = min(irow, T - 1);
         const bf16* qp = a.q + ((size_t)iq * B + b) * a.ld_qkv + h * DH;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -155,14 +187,23 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
             for (int e = 0; e < 8; ++e) {
                 const int f = h * DH + 32 * ks + 8 * g + e;
                 const float x = bf2f(raw[e]);
-                qu[ks][e] = f2bf(x + a.u[f]);
-                qv[ks][e] = f2bf(x + a.vb[f]);
+                qu[ks][e] = f2bf((x + a.u[f]) * c2);
+                qv[ks][e] = f2bf((x + a.vb[f]) * c2);
+            }
+            if (a.qu2 != nullptr && irow < T) {
+                const size_t off = ((size_t)irow * B + b) * (a.H * DH) + h * DH + 32 * ks + 8 * g;
+                st_bf16x8(a.qu2 + off, qu[ks]);
+                st_bf16x8(a.qv2 + off, qv[ks]);
             }
         }
     }
     int srcaddr[4];
+    bool lower[4];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
+    for (int reg = 0; reg < 4; ++reg) {
+        srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
+        lower[reg] = r16 < 4 * g + reg;
+    }
 
     f32x4 o[DB];
 #pragma unroll
@@ -172,15 +213,37 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
 
     int jt_lo, jt_hi;
     kv_range(a, i0, rst, jt_lo, jt_hi);
-    bf16* myP = sP + w * 16 * PP;
-    for (int jt = jt_lo; jt <= jt_hi; ++jt) {
+    bf16* myP = sP + w * 64 * PT;
+
+    const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
+    const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
+    Stager<64, DH> stK, stV, stR;
+    stK.init(rsb, tid);
+    stV.init(rsb, tid);
+    stR.init((unsigned)a.ld_rd * 2u, tid);
+    const unsigned rdb = (unsigned)a.ld_rd * 2u;
+    auto issue = [&](int jt) {
+        const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
+        stK.load(srdK, (unsigned)j0 * rsb);
+        stV.load(srdV, (unsigned)j0 * rsb);
+        stR.load(srdR, (unsigned)dlo * rdb);            // negative dlo wraps: out of range -> zeros
+    };
+    {   // prologue: high half of the first band, then the first tile
+        const int dhi = i0 + M - jt_lo * 64 - 63 + 64;
+        stR.load(srdR, (unsigned)dhi * rdb);
+        stR.store(sR + 64 * DH);
+        issue(jt_lo);
+        stK.store(sK);
+        stV.store(sV);
+        stR.store(sR);
+    }
+    __syncthreads();
+    const int iw_lo = i0 + 16 * w, iw_hi = iw_lo + 15;
+    for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
         const int j0 = jt * 64;
-        const int dlo = i0 + M - j0 - 63;
-        __syncthreads();
-        stage<64, DH>(sK, a.k + ((size_t)j0 * B + b) * a.ld_qkv + h * DH, rs, 0, K - j0, tid);
-        stage<DH, 64>(sVt, a.vt + (((size_t)b * a.H + h) * DH) * a.Jpad + j0, (size_t)a.Jpad, 0, DH, tid);
-        stage<128, DH>(sR, a.rd + (ptrdiff_t)dlo * a.ld_rd + h * DH, (size_t)a.ld_rd, -dlo, K - dlo, tid);
-        __syncthreads();
+        if (jt < jt_hi) issue(jt + 1);
 
         f32x4 s[4];
 #pragma unroll
@@ -193,54 +256,79 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int prow = ring_row(16 * w + 16 * blk, t) + r16;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qr[blk] = mfma16(qv[ks], frag<DH>(sR, 16 * w + 16 * blk + r16, 4 * ks + g), qr[blk]);
+            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], frag<DH>(sR, prow, 4 * ks + g), qr[blk]);
         }
-        // skew + scale + mask
+        // skew: BD[row][jj] = QR[row][row - jj + 63]
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            float pm[5];
+            // named scalars (not an array): `cond ? pm[a] : pm[b]` would be turned into a dynamic index
+            const float p0 = bperm(srcaddr[reg], qr[0][reg]), p1 = bperm(srcaddr[reg], qr[1][reg]),
+                        p2 = bperm(srcaddr[reg], qr[2][reg]), p3 = bperm(srcaddr[reg], qr[3][reg]),
+                        p4 = bperm(srcaddr[reg], qr[4][reg]);
+            s[0][reg] += lower[reg] ? p4 : p3;
+            s[1][reg] += lower[reg] ? p3 : p2;
+            s[2][reg] += lower[reg] ? p2 : p1;
+            s[3][reg] += lower[reg] ? p1 : p0;
+        }
+        const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
+                               (rst && j0 < M) || (iw_hi >= T);
+        if (need_mask) {
 #pragma unroll
-            for (int blk = 0; blk < 5; ++blk) pm[blk] = bperm(srcaddr[reg], qr[blk][reg]);
-            const int row = 4 * g + reg;
-            const int i = i0 + 16 * w + row;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = iw_lo + 4 * g + reg;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float bd = (r16 < row) ? pm[4 - c] : pm[3 - c];
-                const int j = j0 + 16 * c + r16;
-                const float sc = (s[c][reg] + bd) * a.scale;
-                s[c][reg] = is_masked(i, j, M, a.same_length, a.sshift, rst) ? -INFINITY : sc;
+                for (int c = 0; c < 4; ++c)
+                    if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst)) s[c][reg] = -INFINITY;
             }
         }
-        // online softmax
+        // online softmax (log2 domain); rescale only when some row's running max moved
+        float mnew[4];
+        bool grew = false;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             float mx = fmaxf(fmaxf(s[0][reg], s[1][reg]), fmaxf(s[2][reg], s[3][reg]));
             mx = row16_max(mx);
-            const float mnew = fmaxf(mrow[reg], mx);
-            const float alpha = __expf(mrow[reg] - mnew);
-            mrow[reg] = mnew;
-            float ps = 0.f;
+            mnew[reg] = fmaxf(mrow[reg], mx);
+            grew |= mnew[reg] > mrow[reg];
+        }
+        if (__any(grew)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float p = __expf(s[c][reg] - mnew);
-                ps += p;
-                myP[(4 * g + reg) * PP + 16 * c + r16] = f2bf(p);
+            for (int reg = 0; reg < 4; ++reg) {
+                const float alpha = __builtin_amdgcn_exp2f(mrow[reg] - mnew[reg]);
+                mrow[reg] = mnew[reg];
+                lpart[reg] *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) o[d][reg] *= alpha;
             }
-            lpart[reg] = lpart[reg] * alpha + ps;
+        }
 #pragma unroll
-            for (int d = 0; d < DB; ++d) o[d][reg] *= alpha;
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 pb;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
+                lpart[reg] += p;
+                pb[reg] = f2bf(p);
+            }
+            *(bf16x4*)(myP + (16 * c + r16) * PT + 4 * g) = pb;       // P^T[kv][row]: rows 4g..4g+3
         }
         __builtin_amdgcn_wave_barrier();
-        bf16x8 pf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) pf[ks] = ld_bf16x8(myP + r16 * PP + 32 * ks + 8 * g);
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pf = frag_tr(myP, 32 * ks, r16, g);
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) o[d] = mfma16(pf[ks], frag<64>(sVt, 16 * d + r16, 4 * ks + g), o[d]);
-        __builtin_amdgcn_wave_barrier();
+            for (int d = 0; d < DB; ++d)
+                o[d] = mfma16(pf, frag_tr_rm<DH>(sV, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * d, r16), o[d]);
+        }
+        __syncthreads();
+        if (jt < jt_hi) {
+            stK.store(sK);
+            stV.store(sV);
+            stR.store(sR + (((t + 1) & 1) << 6) * DH);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -251,86 +339,91 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
             bf16* op = a.out + ((size_t)i * B + b) * a.ld_o + h * DH;
 #pragma unroll
             for (int d = 0; d < DB; ++d) op[16 * d + r16] = f2bf(o[d][reg] * inv);
-            if (r16 == 0) a.lse[((size_t)b * a.H + h) * T + i] = mrow[reg] + __logf(l);
+            if (r16 == 0) a.lse[((size_t)b * a.H + h) * T + i] = (mrow[reg] + __log2f(l)) * LN2;
         }
     }
 }
 
 // =============================================================================================
-// backward, q-stationary: dq (= dq_ac + dq_bd), per-block column sums of dq_ac / dq_bd (du, dv
-// bias grads), (q+v) copy and the skewed dS band dSk[i][d] for the dR GEMM.
+// backward, q-stationary: dq_AC = dS.K (+ its column sums for d r_w_bias) and dS written by
+// DISTANCE (dSk[i][d = i+M-j]) for the two GEMMs  dq_BD = dSk.Rd  and  dRd = dSk^T.(q+v).
 template <int DH>
 __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     __shared__ __attribute__((aligned(16))) bf16 sK[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sKt[DH * 64];
     __shared__ __attribute__((aligned(16))) bf16 sV[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sR[128 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sRt[DH * 128];
-    __shared__ __attribute__((aligned(16))) bf16 sP[4 * 16 * PP];
-    __shared__ __attribute__((aligned(16))) bf16 sP2[4 * 16 * PP2];
-    __shared__ float red[2][4][DH];
+    __shared__ __attribute__((aligned(16))) bf16 sD[4 * 64 * PT];
+    __shared__ float red[4][DH];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int i0 = qt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const size_t rs = (size_t)B * a.ld_qkv;
+    const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;
+    const int HD = a.H * DH;
 
     bf16x8 qu[KS], qv[KS], dof[KS];
     {
-        const int irow = i0 + 16 * w + r16;
-        const int iq = min(irow, T - 1);
-        const bf16* qp = a.q + ((size_t)iq * B + b) * a.ld_qkv + h * DH;
+        const int iq = min(i0 + 16 * w + r16, T - 1);
+        const size_t off = ((size_t)iq * B + b) * HD + h * DH;
         const bf16* dop = a.dout + ((size_t)iq * B + b) * a.ld_o + h * DH;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 raw = ld_bf16x8(qp + 32 * ks + 8 * g);
+            qu[ks] = ld_bf16x8(a.qu2 + off + 32 * ks + 8 * g);
+            qv[ks] = ld_bf16x8(a.qv2 + off + 32 * ks + 8 * g);
             dof[ks] = ld_bf16x8(dop + 32 * ks + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int f = h * DH + 32 * ks + 8 * g + e;
-                const float x = bf2f(raw[e]);
-                qu[ks][e] = f2bf(x + a.u[f]);
-                qv[ks][e] = f2bf(x + a.vb[f]);
-            }
-            if (irow < T)
-                st_bf16x8(a.qv_out + ((size_t)irow * B + b) * (a.H * DH) + h * DH + 32 * ks + 8 * g, qv[ks]);
         }
     }
-    float lse[4], dl[4];
+    float lse2[4], dl[4];
+    int srcaddr[4];
+    bool lower[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int i = min(i0 + 16 * w + 4 * g + reg, T - 1);
-        lse[reg] = a.lse_in[((size_t)b * a.H + h) * T + i];
+        lse2[reg] = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E;
         dl[reg] = a.delta[((size_t)b * a.H + h) * T + i];
+        srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
+        lower[reg] = r16 < 4 * g + reg;
     }
-    int srcaddr[4];
+    f32x4 dq[DB];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
-
-    f32x4 dq_ac[DB], dq_bd[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d) dq_ac[d] = dq_bd[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    bf16* myP = sP + w * 16 * PP;
-    bf16* myP2 = sP2 + w * 16 * PP2;
-    // zero the k-padding columns 80..95 of the dQR tile once
-    for (int i = lane; i < 16 * 16; i += 64) myP2[(i >> 4) * PP2 + 80 + (i & 15)] = f2bf(0.f);
+    for (int d = 0; d < DB; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int jt_lo, jt_hi;
     kv_range(a, i0, rst, jt_lo, jt_hi);
-    const size_t mrow0 = (size_t)a.T * B;        // rows per head in dSk
-    for (int jt = jt_lo; jt <= jt_hi; ++jt) {
+    bf16* myD = sD + w * 64 * PT;
+
+    const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
+    const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
+    Stager<64, DH> stK, stV, stR;
+    stK.init(rsb, tid);
+    stV.init(rsb, tid);
+    stR.init((unsigned)a.ld_rd * 2u, tid);
+    const unsigned rdb = (unsigned)a.ld_rd * 2u;
+    auto issue = [&](int jt) {
+        const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
+        stK.load(srdK, (unsigned)j0 * rsb);
+        stV.load(srdV, (unsigned)j0 * rsb);
+        stR.load(srdR, (unsigned)dlo * rdb);
+    };
+    {
+        const int dhi = i0 + M - jt_lo * 64 - 63 + 64;
+        stR.load(srdR, (unsigned)dhi * rdb);
+        stR.store(sR + 64 * DH);
+        issue(jt_lo);
+        stK.store(sK);
+        stV.store(sV);
+        stR.store(sR);
+    }
+    __syncthreads();
+    const int iw_lo = i0 + 16 * w, iw_hi = iw_lo + 15;
+    const size_t mrow0 = (size_t)T * B;
+    for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
         const int j0 = jt * 64;
-        const int dlo = i0 + M - j0 - 63;
-        __syncthreads();
-        stage<64, DH>(sK, a.k + ((size_t)j0 * B + b) * a.ld_qkv + h * DH, rs, 0, K - j0, tid);
-        stage<64, DH>(sV, a.v + ((size_t)j0 * B + b) * a.ld_qkv + h * DH, rs, 0, K - j0, tid);
-        stage<DH, 64>(sKt, a.kt + (((size_t)b * a.H + h) * DH) * a.Jpad + j0, (size_t)a.Jpad, 0, DH, tid);
-        stage<128, DH>(sR, a.rd + (ptrdiff_t)dlo * a.ld_rd + h * DH, (size_t)a.ld_rd, -dlo, K - dlo, tid);
-        stage<DH, 128>(sRt, a.rdt + ((size_t)h * DH) * a.Wr + (128 + a.sft + dlo), (size_t)a.Wr, 0, DH, tid);
-        __syncthreads();
+        if (jt < jt_hi) issue(jt + 1);
 
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -346,100 +439,117 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int prow = ring_row(16 * w + 16 * blk, t) + r16;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qr[blk] = mfma16(qv[ks], frag<DH>(sR, 16 * w + 16 * blk + r16, 4 * ks + g), qr[blk]);
+            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], frag<DH>(sR, prow, 4 * ks + g), qr[blk]);
         }
-        // dS (in s[c][reg]) then its A-layout copy + the un-skewed band
-        const int dlo_w = dlo + 16 * w;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            float pm[5];
+            const float p0 = bperm(srcaddr[reg], qr[0][reg]), p1 = bperm(srcaddr[reg], qr[1][reg]),
+                        p2 = bperm(srcaddr[reg], qr[2][reg]), p3 = bperm(srcaddr[reg], qr[3][reg]),
+                        p4 = bperm(srcaddr[reg], qr[4][reg]);
+            s[0][reg] += lower[reg] ? p4 : p3;
+            s[1][reg] += lower[reg] ? p3 : p2;
+            s[2][reg] += lower[reg] ? p2 : p1;
+            s[3][reg] += lower[reg] ? p1 : p0;
+        }
+        const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
+                               (rst && j0 < M) || (iw_hi >= T);
+        if (need_mask) {
 #pragma unroll
-            for (int blk = 0; blk < 5; ++blk) pm[blk] = bperm(srcaddr[reg], qr[blk][reg]);
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = iw_lo + 4 * g + reg;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst) || i >= T) s[c][reg] = -INFINITY;
+            }
+        }
+        // dS = P (dP - delta) scale ; keep it in s[c][reg]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x4 db;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);
+                const float ds = p * (dp[c][reg] - dl[reg]) * a.scale;
+                s[c][reg] = ds;
+                db[reg] = f2bf(ds);
+            }
+            *(bf16x4*)(myD + (16 * c + r16) * PT + 4 * g) = db;       // dS^T[kv][row]
+        }
+        // un-skew: dQR[row][b] = dS[row][jj = row + 63 - b]  ->  dSk[i][d = dlo_w + b]
+        const int dlo_w = i0 + M - j0 - 63 + 16 * w;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
             const int row = 4 * g + reg;
-            const int i = i0 + 16 * w + row;
-            float ds[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float bd = (r16 < row) ? pm[4 - c] : pm[3 - c];
-                const int j = j0 + 16 * c + r16;
-                const float sc = (s[c][reg] + bd) * a.scale;
-                const bool msk = is_masked(i, j, M, a.same_length, a.sshift, rst) || (i >= T);
-                const float p = msk ? 0.f : __expf(sc - lse[reg]);
-                ds[c] = p * (dp[c][reg] - dl[reg]) * a.scale;
-                myP[row * PP + 16 * c + r16] = f2bf(ds[c]);
-            }
-            float dsp[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dsp[c] = bperm(srcaddr[reg], ds[c]);
-#pragma unroll
-            for (int blk = 0; blk < 5; ++blk) {
-                const float hi = (blk >= 1) ? dsp[4 - blk] : 0.f;      // c = 4-blk valid for blk>=1
-                const float lo = (blk <= 3) ? dsp[3 - blk] : 0.f;      // c = 3-blk valid for blk<=3
-                const float val = (r16 < row) ? hi : lo;
-                const bf16 vb = f2bf(val);
-                myP2[row * PP2 + 16 * blk + r16] = vb;
-                const int bidx = 16 * blk + r16;
-                const int jj = row + 63 - bidx;
-                const int d = dlo_w + bidx;
-                if (jj >= 0 && jj <= 63 && d >= 0 && d < K && i < T)
-                    a.dsk[((size_t)h * mrow0 + (size_t)i * B + b) * a.ld_dsk + d] = vb;
+            const int i = iw_lo + row;
+            const float e0 = bperm(srcaddr[reg], s[0][reg]), e1 = bperm(srcaddr[reg], s[1][reg]),
+                        e2 = bperm(srcaddr[reg], s[2][reg]), e3 = bperm(srcaddr[reg], s[3][reg]);
+            // block blk takes c = 4-blk on lanes r16 < row, c = 3-blk elsewhere
+            const float v0 = lower[reg] ? 0.f : e3;
+            const float v1 = lower[reg] ? e3 : e2;
+            const float v2 = lower[reg] ? e2 : e1;
+            const float v3 = lower[reg] ? e1 : e0;
+            const float v4 = lower[reg] ? e0 : 0.f;
+            if (i < T) {
+                bf16* drow = a.dsk + ((size_t)h * mrow0 + (size_t)i * B + b) * a.ld_dsk;
+                const int jj0 = row + 63 - r16;          // jj of block 0; block blk: jj0 - 16*blk
+                const int d0 = dlo_w + r16;
+#define COMMU_DSK_STORE(BLK, VAL)                                                           \
+                {                                                                            \
+                    const int jj = jj0 - 16 * (BLK), d = d0 + 16 * (BLK);                    \
+                    if (jj >= 0 && jj <= 63 && d >= 0 && d < K) drow[d] = f2bf(VAL);         \
+                }
+                COMMU_DSK_STORE(0, v0) COMMU_DSK_STORE(1, v1) COMMU_DSK_STORE(2, v2) COMMU_DSK_STORE(3, v3)
+                COMMU_DSK_STORE(4, v4)
+#undef COMMU_DSK_STORE
             }
         }
         __builtin_amdgcn_wave_barrier();
-        bf16x8 pf[2], pf2[3];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) pf[ks] = ld_bf16x8(myP + r16 * PP + 32 * ks + 8 * g);
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 df = frag_tr(myD, 32 * ks, r16, g);
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) pf2[ks] = ld_bf16x8(myP2 + r16 * PP2 + 32 * ks + 8 * g);
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                dq_ac[d] = mfma16(pf[ks], frag<64>(sKt, 16 * d + r16, 4 * ks + g), dq_ac[d]);
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-                dq_bd[d] = mfma16(pf2[ks], frag<128>(sRt, 16 * d + r16, min(2 * w + 4 * ks + g, 15)), dq_bd[d]);
+            for (int d = 0; d < DB; ++d)
+                dq[d] = mfma16(df, frag_tr_rm<DH>(sK, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * d, r16), dq[d]);
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (jt < jt_hi) {
+            stK.store(sK);
+            stV.store(sV);
+            stR.store(sR + (((t + 1) & 1) << 6) * DH);
+        }
+        __syncthreads();
     }
-    // outputs
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
-        float ca = 0.f, cb = 0.f;
+        float ca = 0.f;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int i = i0 + 16 * w + 4 * g + reg;
             if (i < T) {
-                a.dq[((size_t)i * B + b) * a.ld_dqkv + h * DH + 16 * d + r16] = f2bf(dq_ac[d][reg] + dq_bd[d][reg]);
-                ca += dq_ac[d][reg];
-                cb += dq_bd[d][reg];
+                a.dq[((size_t)i * B + b) * HD + h * DH + 16 * d + r16] = f2bf(dq[d][reg]);
+                ca += dq[d][reg];
             }
         }
-        ca += __shfl_xor(ca, 16, 64); ca += __shfl_xor(ca, 32, 64);
-        cb += __shfl_xor(cb, 16, 64); cb += __shfl_xor(cb, 32, 64);
-        if (g == 0) { red[0][w][16 * d + r16] = ca; red[1][w][16 * d + r16] = cb; }
+        ca += __shfl_xor(ca, 16, 64);
+        ca += __shfl_xor(ca, 32, 64);
+        if (g == 0) red[w][16 * d + r16] = ca;
     }
     __syncthreads();
-    if (tid < DH) {
-        const size_t off = ((size_t)b * gridDim.x + qt) * (a.H * DH) + h * DH + tid;
-        a.du_part[off] = red[0][0][tid] + red[0][1][tid] + red[0][2][tid] + red[0][3][tid];
-        a.dvb_part[off] = red[1][0][tid] + red[1][1][tid] + red[1][2][tid] + red[1][3][tid];
-    }
+    if (tid < DH)
+        a.du_part[((size_t)b * gridDim.x + qt) * HD + h * DH + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 // =============================================================================================
 // backward, kv-stationary: dk, dv.  Wave w owns kv columns 16w..16w+15 of the tile; S, dP are
-// held as [64 q rows x 16 kv cols] in C layout, which IS the A-operand layout of S^T / dS^T.
+// held as [64 q rows x 16 kv cols] in C layout, which IS the A-operand layout of P^T / dS^T.
 template <int DH>
 __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     __shared__ __attribute__((aligned(16))) bf16 sQu[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sQv[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sQut[DH * 64];
     __shared__ __attribute__((aligned(16))) bf16 sdO[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sdOt[DH * 64];
     __shared__ __attribute__((aligned(16))) bf16 sR[128 * DH];
     __shared__ float sLse[64], sDl[64];
 
@@ -447,24 +557,26 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
     const int jt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int j0 = jt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const size_t rs = (size_t)B * a.ld_qkv;
+    const int HD = a.H * DH;
 
     bf16x8 kf[KS], vf[KS];
     {
         const int j = j0 + 16 * w + r16;
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16* kp = a.k + ((size_t)min(j, K - 1) * B + b) * a.ld_qkv + h * DH;
-        const bf16* vp = a.v + ((size_t)min(j, K - 1) * B + b) * a.ld_qkv + h * DH;
+        const size_t off = ((size_t)min(j, K - 1) * B + b) * a.ld_qkv + h * DH;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = (j < K) ? ld_bf16x8(kp + 32 * ks + 8 * g) : z;
-            vf[ks] = (j < K) ? ld_bf16x8(vp + 32 * ks + 8 * g) : z;
+            kf[ks] = (j < K) ? ld_bf16x8(a.k + off + 32 * ks + 8 * g) : z;
+            vf[ks] = (j < K) ? ld_bf16x8(a.v + off + 32 * ks + 8 * g) : z;
         }
     }
     int srcaddr[4];
+    bool lower[4];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
-
+    for (int reg = 0; reg < 4; ++reg) {
+        srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
+        lower[reg] = r16 < 4 * g + reg;
+    }
     f32x4 dk[DB], dv[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) dk[d] = dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -476,55 +588,81 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
     if (rst && j0 + 63 < M) it_hi = -1;          // whole tile is reset memory: no gradient
     if (it_hi < it_lo) it_hi = it_lo - 1;
 
-    for (int it = it_lo; it <= it_hi; ++it) {
-        const int i0 = it * 64;
-        const int dlo = i0 + M - j0 - 63;
-        __syncthreads();
-        const bf16* qbase = a.q + ((size_t)i0 * B + b) * a.ld_qkv + h * DH;
-        stage_bias<64, DH>(sQu, qbase, rs, 0, T - i0, a.u + h * DH, tid);
-        stage_bias<64, DH>(sQv, qbase, rs, 0, T - i0, a.vb + h * DH, tid);
-        stage<64, DH>(sdO, a.dout + ((size_t)i0 * B + b) * a.ld_o + h * DH, (size_t)B * a.ld_o, 0, T - i0, tid);
-        stage<DH, 64>(sQut, a.qut + (((size_t)b * a.H + h) * DH) * a.Tpad + i0, (size_t)a.Tpad, 0, DH, tid);
-        stage<DH, 64>(sdOt, a.dot + (((size_t)b * a.H + h) * DH) * a.Tpad + i0, (size_t)a.Tpad, 0, DH, tid);
-        stage<128, DH>(sR, a.rd + (ptrdiff_t)dlo * a.ld_rd + h * DH, (size_t)a.ld_rd, -dlo, K - dlo, tid);
+    const unsigned qsb = (unsigned)B * HD * 2u, osb = (unsigned)B * a.ld_o * 2u, rdb = (unsigned)a.ld_rd * 2u;
+    const srd_t srdQu = make_srd(a.qu2 + (size_t)b * HD + h * DH, ((size_t)(T - 1) * B * HD + DH) * 2);
+    const srd_t srdQv = make_srd(a.qv2 + (size_t)b * HD + h * DH, ((size_t)(T - 1) * B * HD + DH) * 2);
+    const srd_t srdO = make_srd(a.dout + (size_t)b * a.ld_o + h * DH, ((size_t)(T - 1) * B * a.ld_o + DH) * 2);
+    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
+    Stager<64, DH> stQu, stQv, stO, stR;
+    stQu.init(qsb, tid);
+    stQv.init(qsb, tid);
+    stO.init(osb, tid);
+    stR.init(rdb, tid);
+    float plse = 0.f, pdl = 0.f;
+    auto issue = [&](int it, int half) {          // band half `half` of tile `it`
+        const int i0 = it * 64, dlo = i0 + M - j0 - 63;
+        stQu.load(srdQu, (unsigned)i0 * qsb);
+        stQv.load(srdQv, (unsigned)i0 * qsb);
+        stO.load(srdO, (unsigned)i0 * osb);
+        stR.load(srdR, (unsigned)(dlo + 64 * half) * rdb);
         if (tid < 64) {
             const int i = min(i0 + tid, T - 1);
-            sLse[tid] = a.lse_in[((size_t)b * a.H + h) * T + i];
-            sDl[tid] = a.delta[((size_t)b * a.H + h) * T + i];
+            plse = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E;
+            pdl = a.delta[((size_t)b * a.H + h) * T + i];
         }
-        __syncthreads();
+    };
+    auto commit = [&](bf16* rdst) {
+        stQu.store(sQu);
+        stQv.store(sQv);
+        stO.store(sdO);
+        stR.store(rdst);
+        if (tid < 64) { sLse[tid] = plse; sDl[tid] = pdl; }
+    };
+    if (it_lo <= it_hi) {
+        // prologue: low half of the first band (physical half 0), then the tile with its high half
+        const int dlo = it_lo * 64 + M - j0 - 63;
+        stR.load(srdR, (unsigned)dlo * rdb);
+        stR.store(sR);
+        issue(it_lo, 1);
+        commit(sR + 64 * DH);
+    }
+    __syncthreads();
+    for (int it = it_lo, t = 0; it <= it_hi; ++it, ++t) {
+        const int i0 = it * 64;
+        if (it < it_hi) issue(it + 1, 1);
 
-        bf16x4 pb[4], dsb[4];     // per row block: P and dS for rows 16rb + 4g + reg, col r16
+        bf16x4 pb[4], dsb[4];     // per row block: P and dS'' for rows 16rb + 4g + reg, col r16
+        const int jw_lo = j0 + 16 * w, jw_hi = jw_lo + 15;
+        const bool need_mask = (jw_hi > i0 + M) || (a.same_length && jw_lo <= i0 + 63 - a.sshift) ||
+                               (rst && jw_lo < M) || (i0 + 63 >= T) || (jw_hi >= K);
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             f32x4 qr0 = {0.f, 0.f, 0.f, 0.f}, qr1 = {0.f, 0.f, 0.f, 0.f};
-            const int base = 16 * (rb - w) + 48;
+            const int base = 16 * (rb - w) + 48;          // band rows base .. base+31
+            const int pr0 = ring_row(base, t) + r16, pr1 = ring_row(base + 16, t) + r16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 quf = frag<DH>(sQu, 16 * rb + r16, 4 * ks + g);
                 const bf16x8 qvf = frag<DH>(sQv, 16 * rb + r16, 4 * ks + g);
-                s = mfma16(quf, kf[ks], s);
+                s = mfma16(frag<DH>(sQu, 16 * rb + r16, 4 * ks + g), kf[ks], s);
                 dp = mfma16(frag<DH>(sdO, 16 * rb + r16, 4 * ks + g), vf[ks], dp);
-                qr0 = mfma16(qvf, frag<DH>(sR, base + r16, 4 * ks + g), qr0);
-                qr1 = mfma16(qvf, frag<DH>(sR, base + 16 + r16, 4 * ks + g), qr1);
+                qr0 = mfma16(qvf, frag<DH>(sR, pr0, 4 * ks + g), qr0);
+                qr1 = mfma16(qvf, frag<DH>(sR, pr1, 4 * ks + g), qr1);
             }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int row = 4 * g + reg;
                 const float p0 = bperm(srcaddr[reg], qr0[reg]);
                 const float p1 = bperm(srcaddr[reg], qr1[reg]);
-                const float bd = (r16 < row) ? p1 : p0;
-                const int ii = 16 * rb + row;
-                const int i = i0 + ii, j = j0 + 16 * w + r16;
-                const float sc = (s[reg] + bd) * a.scale;
-                const bool msk = is_masked(i, j, M, a.same_length, a.sshift, rst) || (i >= T);
-                const float p = msk ? 0.f : __expf(sc - sLse[ii]);
+                const int ii = 16 * rb + 4 * g + reg;
+                float sc = s[reg] + (lower[reg] ? p1 : p0);
+                if (need_mask && (is_masked(i0 + ii, jw_lo + r16, M, a.same_length, a.sshift, rst) || i0 + ii >= T))
+                    sc = -INFINITY;
+                const float p = __builtin_amdgcn_exp2f(sc - sLse[ii]);
                 pb[rb][reg] = f2bf(p);
-                dsb[rb][reg] = f2bf(p * (dp[reg] - sDl[ii]) * a.scale);
+                dsb[rb][reg] = f2bf(p * (dp[reg] - sDl[ii]) * LN2);       // (q+u) is pre-scaled: scale/c2 = ln2
             }
         }
-        // dv += P^T dO ; dk += dS^T (q+u): k-slots e<4 -> ii = 32pp+4g+e, e>=4 -> ii = 32pp+16+4g+e-4
+        // dv += P^T dO ; dk += dS''^T qu2: k-slots e<4 -> ii = 32pp+4g+e, e>=4 -> ii = 32pp+16+4g+e-4
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             bf16x8 pa, da;
@@ -535,16 +673,13 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
             }
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
-                const bf16x4 x0 = frag4<64>(sdOt, 16 * d + r16, 32 * pp + 4 * g);
-                const bf16x4 x1 = frag4<64>(sdOt, 16 * d + r16, 32 * pp + 16 + 4 * g);
-                const bf16x8 xb = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                dv[d] = mfma16(pa, xb, dv[d]);
-                const bf16x4 y0 = frag4<64>(sQut, 16 * d + r16, 32 * pp + 4 * g);
-                const bf16x4 y1 = frag4<64>(sQut, 16 * d + r16, 32 * pp + 16 + 4 * g);
-                const bf16x8 yb = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
-                dk[d] = mfma16(da, yb, dk[d]);
+                dv[d] = mfma16(pa, frag_tr_rm<DH>(sdO, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * d, r16), dv[d]);
+                dk[d] = mfma16(da, frag_tr_rm<DH>(sQu, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * d, r16), dk[d]);
             }
         }
+        __syncthreads();
+        if (it < it_hi) commit(sR + ((t & 1) << 6) * DH);      // new high half replaces this tile's low half
+        __syncthreads();
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -625,13 +760,18 @@ static void fill_common(AttnArgs& a, const commu_attn_desc* d) {
     a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v; a.rd = (const bf16*)d->rd;
 }
 
-extern "C" int commu_relattn_fwd(const commu_attn_desc* d, const void* vt, int Jpad, void* out, float* lse,
+static bool fits_srd(const commu_attn_desc* d) {
+    const size_t K = (size_t)d->T + d->M;
+    return K * d->B * d->ld_qkv * 2 < 0xFFFF0000ull && K * d->ld_rd * 2 < 0xFFFF0000ull;
+}
+
+extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                                  hipStream_t stream) {
     if (d->T <= 0 || d->B <= 0) return 0;
-    if ((d->ld_qkv % 8) || (d->ld_rd % 8) || (Jpad % 64) || Jpad < ((d->T + d->M + 63) / 64) * 64) return -22;
+    if ((d->ld_qkv % 8) || (d->ld_rd % 8) || !fits_srd(d) || ((qu2 == nullptr) != (qv2 == nullptr))) return -22;
     AttnArgs a = {};
     fill_common(a, d);
-    a.vt = (const bf16*)vt; a.Jpad = Jpad; a.out = (bf16*)out; a.lse = lse;
+    a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
     dim3 grid((d->T + 63) / 64, d->H, d->B);
     if (d->DH == 64) COMMU_LAUNCH(relattn_fwd_kernel<64>, grid, dim3(256), 0, stream, a);
     else if (d->DH == 32) COMMU_LAUNCH(relattn_fwd_kernel<32>, grid, dim3(256), 0, stream, a);
@@ -643,17 +783,14 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, const void* vt, int J
 extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream) {
     if (d->T <= 0 || d->B <= 0) return 0;
     const int K = d->T + d->M;
-    if ((d->ld_qkv % 8) || (d->ld_rd % 8) || (e->Jpad % 64) || (e->Tpad % 64) || (e->Wr % 8) ||
-        e->Jpad < ((K + 63) / 64) * 64 || e->Tpad < ((d->T + 63) / 64) * 64 || e->Wr < 128 + 8 + K + 192)
-        return -22;
+    if ((d->ld_qkv % 8) || (d->ld_rd % 8) || (e->ld_dqkv % 8) || !fits_srd(d) || e->ld_dsk < K) return -22;
     AttnArgs a = {};
     fill_common(a, d);
-    a.o = (const bf16*)e->o; a.dout = (const bf16*)e->dout; a.lse_in = e->lse; a.delta = e->delta;
-    a.kt = (const bf16*)e->kt; a.rdt = (const bf16*)e->rdt; a.qut = (const bf16*)e->qut; a.dot = (const bf16*)e->dot;
-    a.dq = (bf16*)e->dq; a.dk = (bf16*)e->dk; a.dv = (bf16*)e->dv; a.qv_out = (bf16*)e->qv_out;
-    a.dsk = (bf16*)e->dsk; a.du_part = e->du_part; a.dvb_part = e->dvb_part;
-    a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk; a.Jpad = e->Jpad; a.Tpad = e->Tpad; a.Wr = e->Wr;
-    a.sft = (8 - ((d->M + 1) % 8)) % 8;
+    a.dout = (const bf16*)e->dout; a.lse_in = e->lse; a.delta = e->delta;
+    a.qu2 = (bf16*)e->qu2; a.qv2 = (bf16*)e->qv2;
+    a.dq = (bf16*)e->dq_ac; a.dk = (bf16*)e->dk; a.dv = (bf16*)e->dv;
+    a.dsk = (bf16*)e->dsk; a.du_part = e->du_part;
+    a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk;
     dim3 gq((d->T + 63) / 64, d->H, d->B), gk((K + 63) / 64, d->H, d->B);
     if (d->DH == 64) {
         COMMU_LAUNCH(relattn_bwd_q_kernel<64>, gq, dim3(256), 0, stream, a);
@@ -665,8 +802,6 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     COMMU_LAUNCH_CHECK();
     return 0;
 }
-
-extern "C" int commu_attn_rdt_shift(int M) { return (8 - ((M + 1) % 8)) % 8; }
 
 extern "C" int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H,
                                 int DH, hipStream_t stream) {

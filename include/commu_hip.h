@@ -42,9 +42,9 @@ int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, 
  * mode 1: LDS transpose reads (ds_read_b64_tr_b16); mode 0: 16-bit gathers. */
 int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc,
                        size_t slab_stride, int M, int N, int K, int nslices, int mode, hipStream_t stream);
-/* dst[i] (+)= sum_s src[s*stride + i] */
+/* dst[i] = (accumulate ? dst[i] : 0) + alpha * sum_s src[s*stride + i] */
 int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, size_t stride,
-                           int accumulate, hipStream_t stream);
+                           int accumulate, float alpha, hipStream_t stream);
 
 /* ---- embedding (AdaptiveEmbedding.forward, model.py:409-420) and its gradient */
 int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo, int ntok, int D,
@@ -107,31 +107,31 @@ typedef struct commu_attn_desc {
     float scale;                    /* 1/sqrt(d_head), model.py:216 */
 } commu_attn_desc;
 
-/* vt: V transposed per head [B][H][DH][Jpad] (commu_transpose_heads). out: bf16 [T*B][ld_o];
- * lse: fp32 [B][H][T]. */
-int commu_relattn_fwd(const commu_attn_desc* d, const void* vt, int Jpad, void* out, float* lse,
+/* out: bf16 [T*B][ld_o]; lse: fp32 [B][H][T] (natural log).  qu2/qv2 (both or neither): bf16
+ * [T*B][H*DH] copies of (q + r_w_bias) and (q + r_r_bias) times scale*log2(e), the operands the
+ * backward kernels re-use. */
+int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                       hipStream_t stream);
 
+/* Backward of commu_relattn_fwd (autograd of model.py:313-345).  Produces dk, dv, the AC part of dq
+ * and dS indexed by distance; the caller finishes with two GEMMs per head:
+ *   dq[:, h] = dq_ac[:, h] + dsk[h] . Rd[:, h]          (commu_gemm_nt_bf16, RESID)
+ *   dRd[:, h] = dsk[h]^T . qv2[:, h] / (scale*log2 e)   (commu_gemm_tn_bf16)
+ * and d r_w_bias = colsum(dq_ac), d r_r_bias = colsum(dq - dq_ac). */
 typedef struct commu_attn_bwd_desc {
-    const void* o;        /* forward output, bf16 [T*B][ld_o] */
-    const void* dout;     /* its gradient, same layout */
-    const float* lse;     /* [B][H][T] */
-    const float* delta;   /* [B][H][T]  (commu_attn_delta) */
-    const void* kt;       /* K^T      [B][H][DH][Jpad] */
-    const void* rdt;      /* Rd^T     [H][DH][Wr], column 128 + commu_attn_rdt_shift(M) + d */
-    const void* qut;      /* (q+u)^T  [B][H][DH][Tpad] */
-    const void* dot;      /* dO^T     [B][H][DH][Tpad] */
-    void* dq;             /* bf16 rows like q with ld_dqkv */
+    const void* dout;     /* gradient of the forward output, bf16 [T*B][ld_o] */
+    const float* lse;     /* [B][H][T] from the forward */
+    const float* delta;   /* [B][H][T]  sum_f dO*O  (commu_attn_delta) */
+    const void* qu2;      /* from the forward */
+    const void* qv2;
+    void* dq_ac;          /* bf16 [T*B][H*DH] */
     void* dk;             /* bf16 rows like k with ld_dqkv */
     void* dv;
-    void* qv_out;         /* bf16 [T*B][H*DH]  (q + r_r_bias) */
-    void* dsk;            /* bf16 [H][T*B][ld_dsk], zero-initialised: dS indexed by distance */
-    float* du_part;       /* [B*ceil(T/64)][H*DH] column sums of the AC part of dq */
-    float* dvb_part;      /* same for the BD part */
-    int ld_dqkv, ld_dsk, Jpad, Tpad, Wr;
+    void* dsk;            /* bf16 [H][T*B][ld_dsk], ZERO-INITIALISED by the caller */
+    float* du_part;       /* [B*ceil(T/64)][H*DH] column sums of dq_ac per query tile */
+    int ld_dqkv, ld_dsk;
 } commu_attn_bwd_desc;
 int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
-int commu_attn_rdt_shift(int M);
 int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H, int DH,
                      hipStream_t stream);
 /* dst[((b*H+h)*DH+f)*W + off + j] = src[(j*B+b)*ld + h*DH + f] (+ bias[h*DH+f]); zero elsewhere */

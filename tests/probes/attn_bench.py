@@ -1,0 +1,48 @@
+"""Micro-benchmark of the attention kernels at the bench shape (B x H x T, M = 0) for profiling."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "commu-code_amd"))
+import torch  # noqa: E402
+from commu_amd import ops  # noqa: E402
+
+B = int(os.environ.get("AB_B", 16))
+T = int(os.environ.get("AB_T", 1024))
+M = int(os.environ.get("AB_M", 0))
+H, DH = 8, 64
+REPS = int(os.environ.get("AB_REPS", 3))
+WHAT = os.environ.get("AB_WHAT", "fwd,bwd")
+dev = "cuda"
+K = T + M
+HD = H * DH
+g = torch.Generator().manual_seed(0)
+qkv = (torch.randn(K * B, 3 * HD, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+rd = (torch.randn(K, HD, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+u = (torch.randn(HD, generator=g) * 0.3).to(dev)
+vb = (torch.randn(HD, generator=g) * 0.3).to(dev)
+dout = (torch.randn(T * B, HD, generator=g)).to(torch.bfloat16).to(dev)
+q, k, v = qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
+dqkv = torch.zeros_like(qkv)
+drd = torch.zeros(K, HD, device=dev)
+du, dvb = torch.zeros(HD, device=dev), torch.zeros(HD, device=dev)
+
+
+def run():
+    out, lse, qs = ops.relattn_fwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, save_q=True)
+    if "bwd" in WHAT:
+        ops.relattn_bwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, out, dout, lse, qs, dqkv[M * B:, :HD],
+                        dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+
+
+run()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(REPS):
+    run()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / REPS
+kbar = M + (T + 1) / 2
+fl = B * T * 6 * kbar * HD
+print(f"B={B} T={T} M={M}: {dt*1e3:.3f} ms per fwd{'+bwd' if 'bwd' in WHAT else ''}; fwd algorithmic {fl/1e9:.1f} GF")

@@ -315,12 +315,13 @@ def test_relattn_bwd(case):
     g = qkv.to(DEV)
     rst = None if reset is None else reset.to(torch.uint8).to(DEV)
     q, k, v = g[M * B:, :HD], g[:, HD:2 * HD], g[:, 2 * HD:]
-    out, lse, _ = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len)
+    out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len,
+                                 save_q=True)
     dqkv = torch.zeros_like(g)
     drd = torch.zeros(K, HD, device=DEV)
     du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
     o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
-                  dout.to(DEV), lse, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+                  dout.to(DEV), lse, qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
     gref = leaf.grad
     tol = 2.5e-2          # bf16 P/dS operands + bf16 outputs
     assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol, "dq"
