@@ -21,7 +21,8 @@ c_z = C.c_size_t
 class AttnDesc(C.Structure):
     _fields_ = [("q", c_p), ("k", c_p), ("v", c_p), ("rd", c_p), ("r_w_bias", c_p), ("r_r_bias", c_p),
                 ("reset", c_p), ("ld_qkv", c_i), ("ld_rd", c_i), ("ld_o", c_i), ("T", c_i), ("M", c_i),
-                ("B", c_i), ("H", c_i), ("DH", c_i), ("same_length", c_i), ("sshift", c_i), ("scale", c_f)]
+                ("B", c_i), ("H", c_i), ("DH", c_i), ("same_length", c_i), ("sshift", c_i), ("scale", c_f),
+                ("drop_p", c_f), ("drop_seed", C.c_uint)]
 
 
 class AttnBwdDesc(C.Structure):
@@ -31,15 +32,15 @@ class AttnBwdDesc(C.Structure):
 
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
 PROTOTYPES = {
-    "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
+    "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, C.c_uint, c_f, c_f, c_p],
     "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
-    "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
-    "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, c_p],
-    "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, c_p],
-    "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p],
+    "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
+    "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, C.c_uint, c_f, c_p],
+    "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
+    "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_bwd_nblocks": [c_i],
-    "commu_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
+    "commu_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_colsum_bf16": [c_p, c_i, c_i, c_i, c_p, c_p],
     "commu_colsum_f32": [c_p, c_i, c_i, c_i, c_p, c_p],
     "commu_ce_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p],

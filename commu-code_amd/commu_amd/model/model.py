@@ -109,7 +109,8 @@ class RelPartialLearnableDecoderLayer(nn.Module):
 class _Saved:
     """Activations of one forward call kept for its backward."""
     __slots__ = ("T", "M", "B", "tokens", "target", "reset", "h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1",
-                 "rs1", "a", "hid", "z2", "mu2", "rs2", "pd", "hL", "logits", "ce_lse", "same_length", "mem_len")
+                 "rs1", "a", "hid", "z2", "mu2", "rs2", "pd", "hL", "logits", "ce_lse", "same_length", "mem_len",
+                 "p", "patt", "seed")
 
 
 class _XLLoss(torch.autograd.Function):
@@ -318,17 +319,28 @@ class MemTransformerLM(nn.Module):
         lay = [self.layers[i] for i in range(L)]
         sv = _Saved() if need_grad else None
 
-        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight)            # K1
-        pd = ops.posemb(self.pos_emb.inv_freq, K, D)                             # K2 (distance order)
+        # K16 dropout: active in train() mode; one base seed per forward call, one derived seed per site
+        p = float(self.drop.p) if self.training else 0.0
+        patt = float(lay[0].dec_attn.dropatt.p) if (self.training and L > 0) else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p > 0 or patt > 0) else 0
+
+        def ss(site):
+            return ops.site_seed(seed, site)
+
+        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight, drop_p=p, drop_seed=ss(0))     # K1
+        pd = ops.posemb(self.pos_emb.inv_freq, K, D, drop_p=p, drop_seed=ss(1))                      # K2 (distance order)
         hids = [h]
         if need_grad:
             sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
             sv.same_length, sv.mem_len = bool(self.same_length), int(self.mem_len)
+            sv.p, sv.patt, sv.seed = p, patt, seed
             for k in ("h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1", "rs1", "a", "hid", "z2", "mu2", "rs2"):
                 setattr(sv, k, [])
         u, vb = self.r_w_bias, self.r_r_bias
+        h_out = None
         for i in range(L):
             w = self._weights(i)
+            s0 = 16 + 4 * i
             qkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
             cat = None
             if M > 0:                                                            # K4 over [mem; h] (model.py:283-288)
@@ -340,29 +352,35 @@ class MemTransformerLM(nn.Module):
             rd = ops.gemm_nt(pd, w["r"])                                         # K5
             vec, lse, qs = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
                                            T, M, B, H, DH, bool(self.same_length), int(self.mem_len),
-                                           save_q=need_grad)                                   # K6
-            z1 = ops.gemm_nt(vec, w["o"], resid=h)                               # K7
+                                           save_q=need_grad, drop_p=patt, drop_seed=ss(s0))    # K6
+            z1 = ops.gemm_nt(vec, w["o"], resid=h, drop_p=p, drop_seed=ss(s0 + 1))             # K7
             a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)
-            hid = ops.gemm_nt(a, w["w1"], bias=lay[i].pos_ff.CoreNet[0].bias, relu=True)     # K8
-            z2 = ops.gemm_nt(hid, w["w2"], bias=lay[i].pos_ff.CoreNet[3].bias, resid=a)
-            y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias)
+            hid = ops.gemm_nt(a, w["w1"], bias=lay[i].pos_ff.CoreNet[0].bias, relu=True, drop_p=p,
+                              drop_seed=ss(s0 + 2))                                            # K8
+            z2 = ops.gemm_nt(hid, w["w2"], bias=lay[i].pos_ff.CoreNet[3].bias, resid=a, drop_p=p, drop_seed=ss(s0 + 3))
+            if i == L - 1 and p > 0:          # final `self.drop(core_out)` (model.py:601) as a second LN output
+                h_out = torch.empty(TB, D, device=dev, dtype=BF16)
+            y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias,
+                                            y_drop=h_out, drop_p=p, drop_seed=ss(2))
             if need_grad:
                 sv.h.append(h); sv.cat.append(cat); sv.qkv.append(qkv); sv.rd.append(rd); sv.vec.append(vec)
-                sv.lse.append(lse); sv.qs.append(qs); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1); sv.a.append(a)
-                sv.hid.append(hid); sv.z2.append(z2); sv.mu2.append(mu2); sv.rs2.append(rs2)
+                sv.lse.append(lse); sv.qs.append(qs); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1)
+                sv.a.append(a); sv.hid.append(hid); sv.z2.append(z2); sv.mu2.append(mu2); sv.rs2.append(rs2)
             h = y
             hids.append(h)
+        if h_out is None:
+            h_out = h
 
         new_mems = self._update_mems(hids, mems, M, T, B)                        # K9
         logits = torch.empty(TB, VPAD, device=dev, dtype=F32)                    # K10 / K14
-        ops.gemm_nt(h, self._bf16_view("word_emb.emb_layers.0.weight", (V, D)), out=logits[:, :V],
+        ops.gemm_nt(h_out, self._bf16_view("word_emb.emb_layers.0.weight", (V, D)), out=logits[:, :V],
                     bias=self.crit.out_layers[0].bias)
         if want_logits:
             return logits.view(T, B, VPAD)[:, :, :V], new_mems, None
         tgt = target.contiguous().view(-1)
         nll, ce_lse = ops.ce_fwd(logits, tgt, V)
         if need_grad:
-            sv.hL, sv.logits, sv.ce_lse, sv.target = h, logits, ce_lse, tgt
+            sv.hL, sv.logits, sv.ce_lse, sv.target = h_out, logits, ce_lse, tgt
         return nll.view(T, B), new_mems, sv
 
     def _update_mems(self, hids, mems, M, T, B):                                 # model.py:507-538
@@ -418,25 +436,40 @@ class MemTransformerLM(nn.Module):
         ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)))
         gE = gv("word_emb.emb_layers.0.weight", (V, D))
         self._tn_acc(dlogits, sv.hL, gE, rows=V)
-        dy = ops.gemm_nt(dlogits, sh["Et"])                                      # [TB, D]
+        p, patt = sv.p, sv.patt
+        inv_keep = 1.0 / (1.0 - p)
+
+        def ss(site):
+            return ops.site_seed(sv.seed, site)
+
+        dy = ops.gemm_nt(dlogits, sh["Et"], drop_p=p, drop_seed=ss(2))           # [TB, D] (through the final dropout)
         gu, gvb = gv("r_w_bias", (HD,)), gv("r_r_bias", (HD,))
         for i in range(L - 1, -1, -1):
             pre = f"layers.{i}."
             lay = self.layers[i]
-            dz2, part = ops.layernorm_bwd(dy, sv.z2[i], sv.mu2[i], sv.rs2[i], lay.pos_ff.layer_norm.weight)
+            s0 = 16 + 4 * i
+            dz2m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
+            dz2, part = ops.layernorm_bwd(dy, sv.z2[i], sv.mu2[i], sv.rs2[i], lay.pos_ff.layer_norm.weight,
+                                          dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3))
+            if dz2m is None:
+                dz2m = dz2
             ops.colsum(part[:, 0], gv(pre + "pos_ff.layer_norm.weight", (D,)))
             ops.colsum(part[:, 1], gv(pre + "pos_ff.layer_norm.bias", (D,)))
             ops.colsum(part[:, 2], gv(pre + "pos_ff.CoreNet.3.bias", (D,)))
-            self._tn_acc(dz2, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (D, DI)))
-            dhid = ops.gemm_nt(dz2, sh[f"w2_t{i}"], relu_mask=sv.hid[i])
+            self._tn_acc(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (D, DI)))
+            dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
             self._tn_acc(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DI, D)))
             ops.colsum(dhid, gv(pre + "pos_ff.CoreNet.0.bias", (DI,)))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
-            dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight)
+            dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
+            dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
+                                          dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1))
+            if dz1m is None:
+                dz1m = dz1
             ops.colsum(part[:, 0], gv(pre + "dec_attn.layer_norm.weight", (D,)))
             ops.colsum(part[:, 1], gv(pre + "dec_attn.layer_norm.bias", (D,)))
-            self._tn_acc(dz1, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (D, HD)))
-            dvec = ops.gemm_nt(dz1, sh[f"o_t{i}"])
+            self._tn_acc(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (D, HD)))
+            dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]
             dqkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
             if M > 0:
@@ -444,14 +477,15 @@ class MemTransformerLM(nn.Module):
             drd = torch.empty(K, HD, device=dev, dtype=F32)
             ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], self.r_w_bias,
                             self.r_r_bias, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
-                            sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb)
+                            sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
+                            drop_p=patt, drop_seed=ss(s0))
             self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HD, D)))
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HD, D))
             self._tn_acc(dqkv[M * B:], sv.h[i], gW)
             if M > 0:
                 self._tn_acc(dqkv[:M * B, HD:], sv.cat[i], gW[HD:])
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
-        ops.embed_bwd(sv.tokens, dy, gE, accumulate=True)
+        ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0))
         if direct:
             return tuple(None for _ in params)
         return tuple(G[off:off + p.numel()].view(p.shape) for p, off in zip(params, fl["offs"]))

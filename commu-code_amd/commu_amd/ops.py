@@ -14,7 +14,31 @@ import torch
 from . import _lib
 from ._lib import AttnBwdDesc, AttnDesc, CommuHipError, call
 
-EPI_BIAS, EPI_RELU, EPI_RESID, EPI_RELUMASK, EPI_OUT_F32 = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_RELU, EPI_RESID, EPI_RELUMASK, EPI_OUT_F32, EPI_DROPOUT = 1, 2, 4, 8, 16, 32
+
+
+def site_seed(base_seed: int, site: int) -> int:
+    """32-bit seed of one dropout site of one forward call (host-side integer hash)."""
+    x = (base_seed * 0x9E3779B9 + site * 0x85EBCA6B + 0x165667B1) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_keep_mask(seed: int, n: int, p: float, device="cpu"):
+    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests)."""
+    idx = (torch.arange(n, dtype=torch.int64, device=device) + seed) & 0xFFFFFFFF
+    x = idx
+    x = x ^ (x >> 16)
+    x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    thr = min(int(p * 4294967296.0), 4294967295) if p > 0 else 0
+    return x >= thr
 BF16 = torch.bfloat16
 F32 = torch.float32
 
@@ -40,8 +64,10 @@ def _rowmajor2d(t: torch.Tensor, name: str):
     return t.stride(0)
 
 
-def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None, out_f32=False):
-    """out[M,N] = A[M,K] @ B[N,K]^T (+bias)(+resid)(relu)(relu-mask).  A, B bf16."""
+def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None, out_f32=False,
+            drop_p=0.0, drop_seed=0, mask_scale=1.0):
+    """out[M,N] = A[M,K] @ B[N,K]^T with the fused epilogue bias -> relu -> dropout -> +resid ->
+    relu-mask (kept values * mask_scale).  A, B bf16."""
     lda, ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
     M, K = A.shape
     N = B.shape[0]
@@ -63,9 +89,12 @@ def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None
         assert relu_mask.dtype == BF16
     if out.dtype == F32:
         flags |= EPI_OUT_F32
+    if drop_p > 0:
+        flags |= EPI_DROPOUT
     call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid),
          0 if resid is None else _rowmajor2d(resid, "resid"), _p(relu_mask),
-         0 if relu_mask is None else _rowmajor2d(relu_mask, "relu_mask"), flags, _s())
+         0 if relu_mask is None else _rowmajor2d(relu_mask, "relu_mask"), flags, int(drop_seed), float(drop_p),
+         float(mask_scale), _s())
     return out
 
 
@@ -110,49 +139,53 @@ def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate, alpha=1.0):
     return dst
 
 
-def embed_fwd(tok, E, out=None):
+def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0):
     ntok = tok.numel()
     D = E.shape[1]
     assert tok.dtype == torch.int64 and E.dtype == F32 and E.is_contiguous() and tok.is_contiguous()
     if out is None:
         out = torch.empty(ntok, D, device=E.device, dtype=BF16)
-    call("commu_embed_fwd", _p(tok), _p(E), _p(out), out.stride(0), ntok, D, math.sqrt(D), _s())
+    call("commu_embed_fwd", _p(tok), _p(E), _p(out), out.stride(0), ntok, D, math.sqrt(D), int(drop_seed),
+         float(drop_p), _s())
     return out
 
 
-def embed_bwd(tok, dX, dE, accumulate=True):
+def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0):
     V, D = dE.shape
     call("commu_embed_bwd", _p(tok), _p(dX), dX.stride(0), _p(dE), tok.numel(), D, V, math.sqrt(D),
-         1 if accumulate else 0, _s())
+         1 if accumulate else 0, int(drop_seed), float(drop_p), _s())
     return dE
 
 
-def posemb(inv_freq, K, D, out=None):
+def posemb(inv_freq, K, D, out=None, drop_p=0.0, drop_seed=0):
     if out is None:
         out = torch.empty(K, D, device=inv_freq.device, dtype=BF16)
-    call("commu_posemb_fwd", _p(inv_freq), _p(out), out.stride(0), K, D, _s())
+    call("commu_posemb_fwd", _p(inv_freq), _p(out), out.stride(0), K, D, int(drop_seed), float(drop_p), _s())
     return out
 
 
-def layernorm_fwd(z, gamma, beta, y=None, mean=None, rstd=None, eps=1e-5):
+def layernorm_fwd(z, gamma, beta, y=None, mean=None, rstd=None, eps=1e-5, y_drop=None, drop_p=0.0, drop_seed=0):
+    """y = LN(z); optionally also y_drop = dropout(y) (second output)."""
     rows, D = z.shape
     y = torch.empty_like(z) if y is None else y
     mean = torch.empty(rows, device=z.device, dtype=F32) if mean is None else mean
     rstd = torch.empty(rows, device=z.device, dtype=F32) if rstd is None else rstd
     call("commu_layernorm_fwd", _p(z), z.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), _p(mean), _p(rstd),
-         rows, D, eps, _s())
+         rows, D, eps, _p(y_drop), 0 if y_drop is None else y_drop.stride(0), int(drop_seed), float(drop_p), _s())
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None):
-    """Returns (dz, part) with part [nblk, 3, D]: partial column sums of dy*xhat, dy, dz."""
+def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, drop_p=0.0, drop_seed=0):
+    """Returns (dz, part) with part [nblk, 3, D]: partial column sums of dy*xhat, dy, dz (or of
+    dz_masked = dz * keep/(1-p) when that second output is requested)."""
     rows, D = z.shape
     nblk = call("commu_layernorm_bwd_nblocks", rows)
     dz = torch.empty_like(z) if dz is None else dz
     if part is None:
         part = torch.empty(nblk, 3, D, device=z.device, dtype=F32)
     call("commu_layernorm_bwd", _p(dy), dy.stride(0), _p(z), z.stride(0), _p(mean), _p(rstd), _p(gamma), _p(dz),
-         dz.stride(0), _p(part), rows, D, _s())
+         dz.stride(0), _p(part), rows, D, _p(dz_masked), 0 if dz_masked is None else dz_masked.stride(0),
+         int(drop_seed), float(drop_p), _s())
     return dz, part[:nblk]
 
 
@@ -240,8 +273,9 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem_len):
+def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem_len, drop_p=0.0, drop_seed=0):
     d = AttnDesc()
+    d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     d.q, d.k, d.v, d.rd = q.data_ptr(), k.data_ptr(), v.data_ptr(), rd.data_ptr()
     d.r_w_bias, d.r_r_bias = u.data_ptr(), vb.data_ptr()
     d.reset = reset.data_ptr() if reset is not None else None
@@ -257,7 +291,7 @@ def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem
 
 
 def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None,
-                save_q=False):
+                save_q=False, drop_p=0.0, drop_seed=0):
     """q: 2-D view [T*B, H*DH] (row stride ld_qkv), k, v: [(T+M)*B, H*DH]; rd: [K, H*DH] by distance.
     Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], (qu2, qv2) or None)."""
     if out is None:
@@ -267,13 +301,13 @@ def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     qs = None
     if save_q:
         qs = (torch.empty(T * B, H * DH, device=q.device, dtype=BF16), torch.empty(T * B, H * DH, device=q.device, dtype=BF16))
-    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len)
+    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len, drop_p, drop_seed)
     call("commu_relattn_fwd", C.byref(d), _p(out), _p(lse), _p(qs[0]) if qs else None, _p(qs[1]) if qs else None, _s())
     return out, lse, qs
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
-                drd, du, dvb):
+                drd, du, dvb, drop_p=0.0, drop_seed=0):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
     drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
     dev = q.device
@@ -287,7 +321,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     dsk = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
     dq_ac = torch.empty(T * B, HD, device=dev, dtype=BF16)
     du_part = torch.empty(B * QT, HD, device=dev, dtype=F32)
-    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len)
+    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len, drop_p, drop_seed)
     e = AttnBwdDesc()
     e.dout, e.lse, e.delta = dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
     e.qu2, e.qv2 = qu2.data_ptr(), qv2.data_ptr()

@@ -80,5 +80,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// K16 dropout: counter-based mask, identical in forward and backward.  keep(seed, idx) is a 32-bit
+// integer hash (lowbias32) of the element index compared with p * 2^32; kept values are scaled by
+// 1/(1-p) (nn.Dropout semantics, commu/model/model.py:166,168,210-211,454,585-586,601).
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned idx, unsigned thr) { return mix32(idx + seed) >= thr; }
+
 __device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *(const bf16x8*)p; }
 __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *(bf16x8*)p = v; }

@@ -10,7 +10,8 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // K1: x[m,:] = E[tok[m],:] * sqrt(D)       (commu/model/model.py:409-420)
 __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
-                                 bf16* __restrict__ out, int ldo, int ntok, int D, float scale) {
+                                 bf16* __restrict__ out, int ldo, int ntok, int D, float scale,
+                                 unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= ntok) return;
     const int lane = threadIdx.x & 63;
@@ -18,7 +19,13 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
     bf16* dst = out + (size_t)m * ldo;
     for (int c = lane * 4; c < D; c += 256) {
         f32x4 v = *(const f32x4*)(src + c);
-        bf16x4 o = {f2bf(v[0] * scale), f2bf(v[1] * scale), f2bf(v[2] * scale), f2bf(v[3] * scale)};
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] * scale;
+            if (drop_thr) x = drop_keep(drop_seed, (unsigned)m * (unsigned)D + (unsigned)(c + e), drop_thr) ? x * drop_scale : 0.f;
+            o[e] = f2bf(x);
+        }
         *(bf16x4*)(dst + c) = o;
     }
 }
@@ -27,7 +34,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
 // atomics, deterministic (V = 729 rows only; the token list is L2 resident).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int64_t* __restrict__ tok, const bf16* __restrict__ dX, int ldx, float* __restrict__ dE,
-    int ntok, int D, float scale, int accumulate) {
+    int ntok, int D, float scale, int accumulate, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     __shared__ int hits[1024];
     __shared__ int nhit;
     const int v = blockIdx.x, tid = threadIdx.x;
@@ -42,11 +49,16 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
         __syncthreads();
         const int n = nhit;
         for (int h = 0; h < n; ++h) {
-            const bf16* row = dX + (size_t)hits[h] * ldx;
+            const int m = hits[h];
+            const bf16* row = dX + (size_t)m * ldx;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = tid + 256 * k;
-                if (c < D) acc[k] += bf2f(row[c]);
+                if (c < D) {
+                    float x = bf2f(row[c]);
+                    if (drop_thr) x = drop_keep(drop_seed, (unsigned)m * (unsigned)D + (unsigned)c, drop_thr) ? x * drop_scale : 0.f;
+                    acc[k] += x;
+                }
             }
         }
         __syncthreads();
@@ -64,14 +76,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 // K2: sinusoid table indexed by DISTANCE d (pos = d): out[d] = [sin(d f) | cos(d f)]
 // (commu/model/model.py:142-147; the reference's row k of pos_emb is distance klen-1-k).
 __global__ void posemb_kernel(const float* __restrict__ inv_freq, bf16* __restrict__ out, int ld,
-                              int K, int D) {
+                              int K, int D, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     const int half = D >> 1;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= K * half) return;
     const int d = idx / half, i = idx - d * half;
     const float ang = (float)d * inv_freq[i];
-    out[(size_t)d * ld + i] = f2bf(sinf(ang));
-    out[(size_t)d * ld + half + i] = f2bf(cosf(ang));
+    float sv = sinf(ang), cv = cosf(ang);
+    if (drop_thr) {
+        sv = drop_keep(drop_seed, (unsigned)d * (unsigned)D + (unsigned)i, drop_thr) ? sv * drop_scale : 0.f;
+        cv = drop_keep(drop_seed, (unsigned)d * (unsigned)D + (unsigned)(half + i), drop_thr) ? cv * drop_scale : 0.f;
+    }
+    out[(size_t)d * ld + i] = f2bf(sv);
+    out[(size_t)d * ld + half + i] = f2bf(cv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -81,7 +98,8 @@ constexpr int LN_MAXC = 2;   // D <= 1024: lane owns 8-element chunks at column 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     const bf16* __restrict__ z, int ldz, const float* __restrict__ gamma,
     const float* __restrict__ beta, bf16* __restrict__ y, int ldy, float* __restrict__ mean,
-    float* __restrict__ rstd, int rows, int D, float eps) {
+    float* __restrict__ rstd, int rows, int D, float eps, bf16* __restrict__ ydrop, int ldyd,
+    unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -112,11 +130,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     for (int c = 0; c < LN_MAXC; ++c) {
         const int col = lane * 8 + 512 * c;
         if (col < D) {
-            bf16x8 o;
+            bf16x8 o, od;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                o[e] = f2bf((x[c][e] - mu) * rs * gamma[col + e] + beta[col + e]);
+            for (int e = 0; e < 8; ++e) {
+                const float v = (x[c][e] - mu) * rs * gamma[col + e] + beta[col + e];
+                o[e] = f2bf(v);
+                if (ydrop != nullptr)
+                    od[e] = f2bf(drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr) ? v * drop_scale : 0.f);
+            }
             st_bf16x8(y + (size_t)row * ldy + col, o);
+            if (ydrop != nullptr) st_bf16x8(ydrop + (size_t)row * ldyd + col, od);
         }
     }
 }
@@ -128,7 +151,8 @@ constexpr int LNB_ROWS = 64;   // rows per block (16 per wave)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ z, int ldz,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-    bf16* __restrict__ dz, int lddz, float* __restrict__ part, int rows, int D) {
+    bf16* __restrict__ dz, int lddz, float* __restrict__ part, int rows, int D, bf16* __restrict__ dzm,
+    int lddzm, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     __shared__ float red[4][3][1024];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float ag[LN_MAXC][8], ab[LN_MAXC][8], az[LN_MAXC][8], gm[LN_MAXC][8];
@@ -170,14 +194,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         for (int c = 0; c < LN_MAXC; ++c) {
             const int col = lane * 8 + 512 * c;
             if (col < D) {
-                bf16x8 o;
+                bf16x8 o, om;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float v = rs * (gy[c][e] - m1 - xh[c][e] * m2);
                     o[e] = f2bf(v);
-                    az[c][e] += bf2f(o[e]);
+                    if (dzm != nullptr) {
+                        // gradient w.r.t. the pre-dropout Linear output that fed this LayerNorm
+                        const float vm = drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr) ? v * drop_scale : 0.f;
+                        om[e] = f2bf(vm);
+                        az[c][e] += bf2f(om[e]);
+                    } else {
+                        az[c][e] += bf2f(o[e]);
+                    }
                 }
                 st_bf16x8(dz + (size_t)row * lddz + col, o);
+                if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, om);
             }
         }
     }
@@ -403,41 +435,50 @@ static inline unsigned cap_blocks(size_t want) {
     return (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
 }
 
+static inline unsigned drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    return p <= 0.f ? 0u : (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
+}
+
 extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, int ldo, int ntok, int D,
-                               float scale, hipStream_t stream) {
+                               float scale, unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (ntok <= 0) return 0;
     if (D % 4) return -22;
     COMMU_LAUNCH(embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, stream, tok, E, (bf16*)out,
-                       ldo, ntok, D, scale);
+                       ldo, ntok, D, scale, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, float* dE, int ntok, int D,
-                               int V, float scale, int accumulate, hipStream_t stream) {
+                               int V, float scale, int accumulate, unsigned drop_seed, float drop_p,
+                               hipStream_t stream) {
     if (D > 1024) return -22;
     COMMU_LAUNCH(embed_bwd_kernel, dim3(V), dim3(256), 0, stream, tok, (const bf16*)dX, ldx, dE,
-                       ntok, D, scale, accumulate);
+                       ntok, D, scale, accumulate, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K, int D, hipStream_t stream) {
+extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K, int D, unsigned drop_seed,
+                                float drop_p, hipStream_t stream) {
     const int n = K * (D / 2);
     if (n <= 0) return 0;
     COMMU_LAUNCH(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_freq, (bf16*)out,
-                       ld, K, D);
+                       ld, K, D, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, const float* beta, void* y,
                                    int ldy, float* mean, float* rstd, int rows, int D, float eps,
+                                   void* y_drop, int ldyd, unsigned drop_seed, float drop_p,
                                    hipStream_t stream) {
     if (rows <= 0) return 0;
     if (D > 1024 || (D % 8) || (ldz % 8) || (ldy % 8)) return -22;
     COMMU_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)z,
-                       ldz, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, D, eps);
+                       ldz, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, D, eps, (bf16*)y_drop, ldyd, drop_seed,
+                       drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -446,12 +487,14 @@ extern "C" int commu_layernorm_bwd_nblocks(int rows) { return (rows + LNB_ROWS -
 
 extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const float* mean,
                                    const float* rstd, const float* gamma, void* dz, int lddz,
-                                   float* part, int rows, int D, hipStream_t stream) {
+                                   float* part, int rows, int D, void* dz_masked, int lddzm,
+                                   unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (rows <= 0) return 0;
     if (D > 1024 || (D % 8)) return -22;
     COMMU_LAUNCH(layernorm_bwd_kernel, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
                        (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz,
-                       part, rows, D);
+                       part, rows, D, (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p),
+                       1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -11,6 +11,7 @@
 // 4 consecutive output columns of one row: 8-byte bf16x4 / 16-byte f32x4 stores.
 #include "common.cuh"
 #include "commu_hip.h"
+#include <math.h>
 
 namespace {
 
@@ -25,7 +26,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
     void* __restrict__ Cv, int ldc, int M, int N, int K,
     const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr,
-    const bf16* __restrict__ rmask, int ldm, int flags, int tiles_n) {
+    const bf16* __restrict__ rmask, int ldm, int flags, int tiles_n, unsigned drop_seed, unsigned drop_thr,
+    float drop_scale, float mask_scale) {
     __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
 
@@ -106,19 +108,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
                 for (int e = 0; e < 4; ++e)
                     if (n + e < N) v[e] += bias[n + e];
             }
+            if (flags & COMMU_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (flags & COMMU_EPI_DROPOUT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = drop_keep(drop_seed, (unsigned)m * (unsigned)N + (unsigned)(n + e), drop_thr) ? v[e] * drop_scale : 0.f;
+            }
             if (flags & COMMU_EPI_RESID) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (n + e < N) v[e] += bf2f(resid[(size_t)m * ldr + n + e]);
             }
-            if (flags & COMMU_EPI_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
             if (flags & COMMU_EPI_RELUMASK) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < N && !(bf2f(rmask[(size_t)m * ldm + n + e]) > 0.f)) v[e] = 0.f;
+                    if (n + e < N) v[e] = (bf2f(rmask[(size_t)m * ldm + n + e]) > 0.f) ? v[e] * mask_scale : 0.f;
             }
             if (OUT_F32) {
                 float* C = (float*)Cv + (size_t)m * ldc + n;
@@ -313,19 +320,22 @@ __global__ void reduce_slabs_kernel(float* __restrict__ dst, const float* __rest
 
 extern "C" int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                                   int M, int N, int K, const float* bias, const void* resid, int ldr,
-                                  const void* relu_mask, int ldm, int flags, hipStream_t stream) {
+                                  const void* relu_mask, int ldm, int flags, unsigned drop_seed, float drop_p,
+                                  float mask_scale, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K % BK) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n);
+    const unsigned drop_thr = (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0);
+    const float drop_scale = 1.f / (1.f - drop_p);
     if (flags & COMMU_EPI_OUT_F32)
         COMMU_LAUNCH(gemm_nt_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
                            (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
-                           (const bf16*)relu_mask, ldm, flags, tiles_n);
+                           (const bf16*)relu_mask, ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale);
     else
         COMMU_LAUNCH(gemm_nt_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
                            (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
-                           (const bf16*)relu_mask, ldm, flags, tiles_n);
+                           (const bf16*)relu_mask, ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -51,6 +51,8 @@ struct AttnArgs {
     int T, M, B, H;
     int same_length, sshift;
     float scale;
+    unsigned drop_seed, drop_thr;   // attention-probability dropout (thr == 0: off)
+    float drop_scale;
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
     const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int i0 = qt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
+    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;           // bytes between consecutive kv rows
     const float c2 = a.scale * LOG2E;
 
@@ -308,8 +311,11 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
             bf16x4 pb;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
-                lpart[reg] += p;
+                float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
+                lpart[reg] += p;                               // the normaliser is the un-dropped sum
+                if (a.drop_thr)
+                    p = drop_keep(seed_bh, (unsigned)(iw_lo + 4 * g + reg) * (unsigned)K + (unsigned)(j0 + 16 * c + r16),
+                                  a.drop_thr) ? p * a.drop_scale : 0.f;
                 pb[reg] = f2bf(p);
             }
             *(bf16x4*)(myP + (16 * c + r16) * PT + 4 * g) = pb;       // P^T[kv][row]: rows 4g..4g+3
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
     const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int i0 = qt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
+    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;
     const int HD = a.H * DH;
 
@@ -471,7 +478,11 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);
-                const float ds = p * (dp[c][reg] - dl[reg]) * a.scale;
+                float dpe = dp[c][reg];
+                if (a.drop_thr)
+                    dpe = drop_keep(seed_bh, (unsigned)(iw_lo + 4 * g + reg) * (unsigned)K + (unsigned)(j0 + 16 * c + r16),
+                                    a.drop_thr) ? dpe * a.drop_scale : 0.f;
+                const float ds = p * (dpe - dl[reg]) * a.scale;
                 s[c][reg] = ds;
                 db[reg] = f2bf(ds);
             }
@@ -557,6 +568,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
     const int jt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int j0 = jt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
+    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
     const int HD = a.H * DH;
 
     bf16x8 kf[KS], vf[KS];
@@ -658,8 +670,14 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
                 if (need_mask && (is_masked(i0 + ii, jw_lo + r16, M, a.same_length, a.sshift, rst) || i0 + ii >= T))
                     sc = -INFINITY;
                 const float p = __builtin_amdgcn_exp2f(sc - sLse[ii]);
-                pb[rb][reg] = f2bf(p);
-                dsb[rb][reg] = f2bf(p * (dp[reg] - sDl[ii]) * LN2);       // (q+u) is pre-scaled: scale/c2 = ln2
+                float pd = p, dpe = dp[reg];
+                if (a.drop_thr) {
+                    const bool keep = drop_keep(seed_bh, (unsigned)(i0 + ii) * (unsigned)K + (unsigned)(jw_lo + r16), a.drop_thr);
+                    pd = keep ? p * a.drop_scale : 0.f;
+                    dpe = keep ? dpe * a.drop_scale : 0.f;
+                }
+                pb[rb][reg] = f2bf(pd);
+                dsb[rb][reg] = f2bf(p * (dpe - sDl[ii]) * LN2);           // (q+u) is pre-scaled: scale/c2 = ln2
             }
         }
         // dv += P^T dO ; dk += dS''^T qu2: k-slots e<4 -> ii = 32pp+4g+e, e>=4 -> ii = 32pp+16+4g+e-4
@@ -757,6 +775,9 @@ static void fill_common(AttnArgs& a, const commu_attn_desc* d) {
     a.ld_qkv = d->ld_qkv; a.ld_rd = d->ld_rd; a.ld_o = d->ld_o;
     a.T = d->T; a.M = d->M; a.B = d->B; a.H = d->H;
     a.same_length = d->same_length; a.sshift = d->sshift; a.scale = d->scale;
+    a.drop_seed = d->drop_seed;
+    a.drop_thr = d->drop_p > 0.f ? (unsigned)((double)d->drop_p * 4294967296.0) : 0u;
+    a.drop_scale = 1.f / (1.f - d->drop_p);
     a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v; a.rd = (const bf16*)d->rd;
 }
 

@@ -32,12 +32,15 @@ enum {
     COMMU_EPI_RELU = 2,      /* C = max(C, 0)                   (nn.ReLU, model.py:165)            */
     COMMU_EPI_RESID = 4,     /* C += resid[m, n] (bf16)         (w + attn_out / inp + core_out)    */
     COMMU_EPI_RELUMASK = 8,  /* C = relu_mask[m,n] > 0 ? C : 0  (ReLU backward)                    */
-    COMMU_EPI_OUT_F32 = 16   /* C is fp32 (default bf16)                                           */
+    COMMU_EPI_OUT_F32 = 16,  /* C is fp32 (default bf16)                                           */
+    COMMU_EPI_DROPOUT = 32   /* C = keep(drop_seed, m*N+n) ? C/(1-p) : 0  (nn.Dropout, model.py:166,168,210) */
 };
-/* C[M,N] = A[M,K] . B[N,K]^T with fused epilogue.  K % 32 == 0, lda/ldb % 8 == 0. */
+/* C[M,N] = A[M,K] . B[N,K]^T with fused epilogue, applied in this order: bias, relu, dropout, resid,
+ * relu-mask (kept values times mask_scale).  K % 32 == 0, lda/ldb % 8 == 0, ldc % 4 == 0. */
 int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,
                        int K, const float* bias, const void* resid, int ldr, const void* relu_mask,
-                       int ldm, int flags, hipStream_t stream);
+                       int ldm, int flags, unsigned drop_seed, float drop_p, float mask_scale,
+                       hipStream_t stream);
 /* slabs[s][n,k] = sum_{m in slice s} A[m,n] * B[m,k]  (weight gradients dW = dY^T X).
  * mode 1: LDS transpose reads (ds_read_b64_tr_b16); mode 0: 16-bit gathers. */
 int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc,
@@ -47,21 +50,29 @@ int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, s
                            int accumulate, float alpha, hipStream_t stream);
 
 /* ---- embedding (AdaptiveEmbedding.forward, model.py:409-420) and its gradient */
+/* (drop_p > 0: dropout of the scaled embedding, `core_out = self.drop(word_emb)`, model.py:585;
+ *  every dropout in this ABI is the counter-based mask keep(seed, element index)) */
 int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo, int ntok, int D,
-                    float scale, hipStream_t stream);
+                    float scale, unsigned drop_seed, float drop_p, hipStream_t stream);
 int commu_embed_bwd(const int64_t* tok, const void* dX_bf16, int ldx, float* dE, int ntok, int D, int V,
-                    float scale, int accumulate, hipStream_t stream);
+                    float scale, int accumulate, unsigned drop_seed, float drop_p, hipStream_t stream);
 /* sinusoid table by distance d: out[d] = [sin(d f) | cos(d f)]  (PositionalEmbedding, model.py:136-152) */
-int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, hipStream_t stream);
+int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, unsigned drop_seed,
+                     float drop_p, hipStream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm at model.py:171,214; applied :179,352) */
+/* y_drop (optional): a second output dropout(y) (the final `self.drop(core_out)`, model.py:601) */
 int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, const float* beta, void* y, int ldy,
-                        float* mean, float* rstd, int rows, int D, float eps, hipStream_t stream);
+                        float* mean, float* rstd, int rows, int D, float eps, void* y_drop, int ldyd,
+                        unsigned drop_seed, float drop_p, hipStream_t stream);
 int commu_layernorm_bwd_nblocks(int rows);
 /* part: [nblocks][3][D] partial column sums of (dy*xhat, dy, dz) */
+/* dz_masked (optional): dz through the dropout that followed the Linear feeding this LayerNorm
+ * (dz * keep/(1-p)); when given, part[:,2] holds ITS column sums (that Linear's bias gradient). */
 int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const float* mean,
                         const float* rstd, const float* gamma, void* dz, int lddz, float* part, int rows,
-                        int D, hipStream_t stream);
+                        int D, void* dz_masked, int lddzm, unsigned drop_seed, float drop_p,
+                        hipStream_t stream);
 /* out[c] += sum_r X[r,c]   (bias gradients) */
 int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
 int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
@@ -105,6 +116,8 @@ typedef struct commu_attn_desc {
     int T, M, B, H, DH;
     int same_length, sshift;        /* same_length mask: j <= i - sshift is masked (model.py:549-568) */
     float scale;                    /* 1/sqrt(d_head), model.py:216 */
+    float drop_p;                   /* attention-probability dropout (self.dropatt, model.py:337); 0 = off */
+    unsigned drop_seed;
 } commu_attn_desc;
 
 /* out: bf16 [T*B][ld_o]; lse: fp32 [B][H][T] (natural log).  qu2/qv2 (both or neither): bf16

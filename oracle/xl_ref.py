@@ -130,8 +130,12 @@ def rel_attention_scores(q: Tensor, k: Tensor, r: Tensor, u: Tensor, v: Tensor) 
     return AC + BD
 
 
+def _nodrop(site, x):
+    return x
+
+
 def attn_block(p: Dict[str, Tensor], li: int, s: XLShape, h: Tensor, mem: Optional[Tensor],
-               pos: Tensor, mask: Tensor) -> Tensor:
+               pos: Tensor, mask: Tensor, drop=_nodrop) -> Tensor:
     """RelPartialLearnableMultiHeadAttn.forward in eval mode (model.py:280-354):
     fused QKV over [mem; h], R projection, rel-pos scores, masked softmax, PV, o_net, post-LN."""
     pre = f"layers.{li}."
@@ -147,28 +151,28 @@ def attn_block(p: Dict[str, Tensor], li: int, s: XLShape, h: Tensor, mem: Option
     r = (pos @ p[pre + "dec_attn.r_net.weight"].t()).reshape(K, H, dh)
     S = rel_attention_scores(q, k, r, p["r_w_bias"], p["r_r_bias"]) * (1.0 / math.sqrt(dh))
     S = S.masked_fill(mask[:, None], float("-inf"))
-    A = torch.softmax(S, dim=3)
+    A = drop(("att", li), torch.softmax(S, dim=3))                      # dropatt, model.py:337
     o = torch.einsum("bnij,jbnd->ibnd", A, v).reshape(T, B, H * dh)
-    return layer_norm(h + o @ p[pre + "dec_attn.o_net.weight"].t(),
+    return layer_norm(h + drop(("o", li), o @ p[pre + "dec_attn.o_net.weight"].t()),      # drop, model.py:349
                       p[pre + "dec_attn.layer_norm.weight"], p[pre + "dec_attn.layer_norm.bias"])
 
 
-def ff_block(p: Dict[str, Tensor], li: int, a: Tensor) -> Tensor:
-    """PositionwiseFF.forward in eval mode (model.py:163-181): Linear-ReLU-Linear, post-LN."""
+def ff_block(p: Dict[str, Tensor], li: int, a: Tensor, drop=_nodrop) -> Tensor:
+    """PositionwiseFF.forward (model.py:163-181): Linear-ReLU-Dropout-Linear-Dropout, post-LN."""
     pre = f"layers.{li}."
-    f = torch.relu(a @ p[pre + "pos_ff.CoreNet.0.weight"].t() + p[pre + "pos_ff.CoreNet.0.bias"])
-    f = f @ p[pre + "pos_ff.CoreNet.3.weight"].t() + p[pre + "pos_ff.CoreNet.3.bias"]
+    f = drop(("hid", li), torch.relu(a @ p[pre + "pos_ff.CoreNet.0.weight"].t() + p[pre + "pos_ff.CoreNet.0.bias"]))
+    f = drop(("out", li), f @ p[pre + "pos_ff.CoreNet.3.weight"].t() + p[pre + "pos_ff.CoreNet.3.bias"])
     return layer_norm(a + f, p[pre + "pos_ff.layer_norm.weight"], p[pre + "pos_ff.layer_norm.bias"])
 
 
 def decoder_layer(p: Dict[str, Tensor], li: int, s: XLShape, h: Tensor, mem: Optional[Tensor],
-                  pos: Tensor, mask: Tensor) -> Tensor:
+                  pos: Tensor, mask: Tensor, drop=_nodrop) -> Tensor:
     """RelPartialLearnableDecoderLayer.forward (model.py:370-377)."""
-    return ff_block(p, li, attn_block(p, li, s, h, mem, pos, mask))
+    return ff_block(p, li, attn_block(p, li, s, h, mem, pos, mask, drop), drop)
 
 
 def forward_hidden(p: Dict[str, Tensor], s: XLShape, tokens: Tensor, reset: Optional[Tensor],
-                   mems: Optional[Tensor], mem_len: int, same_length: bool
+                   mems: Optional[Tensor], mem_len: int, same_length: bool, drop=_nodrop
                    ) -> Tuple[Tensor, Optional[Tensor]]:
     """MemTransformerLM._forward in eval mode (model.py:540-604).
 
@@ -177,15 +181,15 @@ def forward_hidden(p: Dict[str, Tensor], s: XLShape, tokens: Tensor, reset: Opti
     T, B = tokens.shape
     D = s.d_model
     E = p["word_emb.emb_layers.0.weight"]
-    h = E[tokens] * math.sqrt(D)
+    h = drop(("emb", 0), E[tokens] * math.sqrt(D))                      # model.py:585
     M = 0 if mems is None or mems.numel() == 0 else mems.shape[1]
     K = T + M
     mask = attn_mask(T, M, B, reset, same_length, mem_len)
-    pos = sinusoid_table(K, D, h.dtype)
+    pos = drop(("pos", 0), sinusoid_table(K, D, h.dtype))               # model.py:586
     hids = [h]
     for li in range(s.n_layer):
         mem = None if M == 0 else mems[li]
-        h = decoder_layer(p, li, s, h, mem, pos, mask)
+        h = decoder_layer(p, li, s, h, mem, pos, mask, drop)
         hids.append(h)
     new_mems = None
     if mems is not None:
@@ -195,7 +199,7 @@ def forward_hidden(p: Dict[str, Tensor], s: XLShape, tokens: Tensor, reset: Opti
         end = M + T
         beg = max(0, end - mem_len)
         new_mems = cat[:, beg:end]
-    return h, new_mems
+    return drop(("final", 0), h), new_mems                              # model.py:601 (mems hold the un-dropped h)
 
 
 def init_mems(s: XLShape, mem_len: int, dtype=torch.float32) -> Optional[Tensor]:
@@ -209,11 +213,12 @@ def logits_from_hidden(p: Dict[str, Tensor], hidden: Tensor) -> Tensor:
 
 
 def forward_loss(p, s: XLShape, data: Tensor, target: Tensor, reset, mems, mem_len: int,
-                 same_length: bool) -> Tuple[Tensor, Optional[Tensor]]:
-    """MemTransformerLM.forward (model.py:678-693): per-token NLL [T,B] and new mems."""
+                 same_length: bool, drop=_nodrop) -> Tuple[Tensor, Optional[Tensor]]:
+    """MemTransformerLM.forward (model.py:678-693): per-token NLL [T,B] and new mems.
+    `drop(site, x)` (optional) applies a dropout mask at the reference's nn.Dropout sites."""
     if mems is None:
         mems = init_mems(s, mem_len, p["r_w_bias"].dtype)
-    hidden, new_mems = forward_hidden(p, s, data, reset, mems, mem_len, same_length)
+    hidden, new_mems = forward_hidden(p, s, data, reset, mems, mem_len, same_length, drop)
     logits = logits_from_hidden(p, hidden)
     lse = torch.logsumexp(logits, dim=-1)
     nll = lse - torch.gather(logits, 2, target[..., None]).squeeze(-1)
