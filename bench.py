@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--mem-len", dest="mem_len", type=int, default=0)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
     ap.add_argument("--batch-chunk", type=int, default=1)
-    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
