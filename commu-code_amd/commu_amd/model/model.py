@@ -301,7 +301,7 @@ class MemTransformerLM(nn.Module):
                 "w1": bv(pre + "pos_ff.CoreNet.0.weight", (DI, D)),
                 "w2": bv(pre + "pos_ff.CoreNet.3.weight", (D, DI))}
 
-    def _run_forward(self, data, target, reset, mems, need_grad, want_logits=False):
+    def _run_forward(self, data, target, reset, mems, need_grad, want_logits=False, want_kv=False):
         fl = self._ensure_flat()
         dev = fl["dev"]
         if not data.is_cuda:
@@ -338,6 +338,7 @@ class MemTransformerLM(nn.Module):
                 setattr(sv, k, [])
         u, vb = self.r_w_bias, self.r_r_bias
         h_out = None
+        kv_out = []
         for i in range(L):
             w = self._weights(i)
             s0 = 16 + 4 * i
@@ -366,6 +367,8 @@ class MemTransformerLM(nn.Module):
                 sv.h.append(h); sv.cat.append(cat); sv.qkv.append(qkv); sv.rd.append(rd); sv.vec.append(vec)
                 sv.lse.append(lse); sv.qs.append(qs); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1)
                 sv.a.append(a); sv.hid.append(hid); sv.z2.append(z2); sv.mu2.append(mu2); sv.rs2.append(rs2)
+            if want_kv:
+                kv_out.append(qkv)
             h = y
             hids.append(h)
         if h_out is None:
@@ -376,7 +379,7 @@ class MemTransformerLM(nn.Module):
         ops.gemm_nt(h_out, self._bf16_view("word_emb.emb_layers.0.weight", (V, D)), out=logits[:, :V],
                     bias=self.crit.out_layers[0].bias)
         if want_logits:
-            return logits.view(T, B, VPAD)[:, :, :V], new_mems, None
+            return logits.view(T, B, VPAD)[:, :, :V], new_mems, (kv_out if want_kv else None)
         tgt = target.contiguous().view(-1)
         nll, ce_lse = ops.ce_fwd(logits, tgt, V)
         if need_grad:

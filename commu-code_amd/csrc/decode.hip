@@ -1,0 +1,146 @@
+// Single-token decode step of the generation loop with a per-layer K/V cache (gfx950).
+//
+// Reference: InferenceTask.calc_logits_and_mems -> MemTransformerLM.forward_generate with qlen = 1
+// (commu/midi_generator/midi_inferrer.py:199-207, commu/model/model.py:606-628).  The reference
+// keeps the per-layer hidden states ("mems") and re-projects K and V of the WHOLE memory on every
+// step (model.py:283-288); with fixed weights the projections are identical each time, so they are
+// cached instead ([B][Lmax][H*DH] per layer, batch-major, bf16) and a step reads each cached row
+// once: HBM-bound.  Sequences are independent and RAGGED: klen[b] is the number of valid rows of
+// sequence b; the new token has position klen[b] and attends to rows 0..klen[b] with distance
+// d = klen[b] - j.  A step whose result the reference discards (quirk Q3) or a sequence that is not
+// stepping simply does not advance klen[b].
+//
+//  kv_append : cache[b][klen[b]] = (k, v) of the new token (active sequences only)
+//  decode_attn: one workgroup per (b, h): scores lane-per-key, softmax in LDS, P.V lane-per-feature
+#include "common.cuh"
+#include "commu_hip.h"
+
+namespace {
+
+__global__ void kv_append_kernel(const bf16* __restrict__ qkv, int ld_qkv, bf16* __restrict__ kc,
+                                 bf16* __restrict__ vc, const int* __restrict__ klen,
+                                 const unsigned char* __restrict__ active, int B, int Lmax, int HD) {
+    const int b = blockIdx.x;
+    if (active != nullptr && !active[b]) return;
+    const int pos = klen[b];
+    if (pos >= Lmax) return;
+    const bf16* src = qkv + (size_t)b * ld_qkv;
+    bf16* kd = kc + ((size_t)b * Lmax + pos) * HD;
+    bf16* vd = vc + ((size_t)b * Lmax + pos) * HD;
+    for (int c = threadIdx.x * 8; c < HD; c += blockDim.x * 8) {
+        st_bf16x8(kd + c, ld_bf16x8(src + HD + c));
+        st_bf16x8(vd + c, ld_bf16x8(src + 2 * HD + c));
+    }
+}
+
+constexpr int DEC_MAXK = 4224;      // >= 4146 + 1 (memory_length of the inference config) rounded up
+
+template <int DH>
+__global__ __launch_bounds__(256) void decode_attn_kernel(
+    const bf16* __restrict__ qkv, int ld_qkv, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+    const bf16* __restrict__ rd, int ld_rd, const float* __restrict__ u, const float* __restrict__ vb,
+    const int* __restrict__ klen, const unsigned char* __restrict__ active, bf16* __restrict__ out, int ld_o,
+    int H, int Lmax, float scale) {
+    __shared__ float sS[DEC_MAXK];
+    __shared__ float sQu[DH], sQv[DH];
+    __shared__ float red[8];
+    __shared__ float sO[4][DH];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    if (active != nullptr && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = min(klen[b] + 1, Lmax);              // keys 0..klen[b] (the new token included)
+    const int HD = H * DH;
+    if (tid < DH) {
+        const float q = bf2f(qkv[(size_t)b * ld_qkv + h * DH + tid]);
+        sQu[tid] = q + u[h * DH + tid];
+        sQv[tid] = q + vb[h * DH + tid];
+    }
+    __syncthreads();
+    const bf16* kb = kc + (size_t)b * Lmax * HD + h * DH;
+    const bf16* vbp = vc + (size_t)b * Lmax * HD + h * DH;
+    // ---- scores: one key per thread
+    float mx = -3.0e38f;
+    for (int j = tid; j < n; j += 256) {
+        const int d = (n - 1) - j;
+        const bf16* kr = kb + (size_t)j * HD;
+        const bf16* rr = rd + (size_t)d * ld_rd + h * DH;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH; c += 8) {
+            const bf16x8 kk = ld_bf16x8(kr + c), r8 = ld_bf16x8(rr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += sQu[c + e] * bf2f(kk[e]) + sQv[c + e] * bf2f(r8[e]);
+        }
+        s *= scale;
+        sS[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float p = __expf(sS[j] - mx);
+        sS[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + w] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    // ---- P.V: wave w takes keys w, w+4, ...; lane = feature (DH <= 64)
+    float acc = 0.f;
+    if (lane < DH) {
+        for (int j = w; j < n; j += 4) acc += sS[j] * bf2f(vbp[(size_t)j * HD + lane]);
+        sO[w][lane] = acc;
+    }
+    __syncthreads();
+    if (tid < DH) out[(size_t)b * ld_o + h * DH + tid] = f2bf((sO[0][tid] + sO[1][tid] + sO[2][tid] + sO[3][tid]) * inv);
+}
+
+__global__ void klen_advance_kernel(int* __restrict__ klen, const unsigned char* __restrict__ advance, int B,
+                                    int Lmax) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && advance[b] && klen[b] < Lmax - 1) klen[b] += 1;
+}
+
+}  // namespace
+
+extern "C" int commu_decode_kv_append(const void* qkv, int ld_qkv, void* kcache, void* vcache, const int* klen,
+                                      const unsigned char* active, int B, int Lmax, int HD, hipStream_t stream) {
+    if (B <= 0) return 0;
+    if ((HD % 8) || (ld_qkv % 8)) return -22;
+    COMMU_LAUNCH(kv_append_kernel, dim3(B), dim3(64), 0, stream, (const bf16*)qkv, ld_qkv, (bf16*)kcache,
+                 (bf16*)vcache, klen, active, B, Lmax, HD);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_decode_attn(const void* qkv, int ld_qkv, const void* kcache, const void* vcache,
+                                 const void* rd, int ld_rd, const float* r_w_bias, const float* r_r_bias,
+                                 const int* klen, const unsigned char* active, void* out, int ld_o, int B, int H,
+                                 int DH, int Lmax, float scale, hipStream_t stream) {
+    if (B <= 0) return 0;
+    if (Lmax > DEC_MAXK || (ld_qkv % 8) || (ld_rd % 8)) return -22;
+    dim3 grid(B * H);
+    if (DH == 64)
+        COMMU_LAUNCH(decode_attn_kernel<64>, grid, dim3(256), 0, stream, (const bf16*)qkv, ld_qkv,
+                     (const bf16*)kcache, (const bf16*)vcache, (const bf16*)rd, ld_rd, r_w_bias, r_r_bias, klen,
+                     active, (bf16*)out, ld_o, H, Lmax, scale);
+    else if (DH == 32)
+        COMMU_LAUNCH(decode_attn_kernel<32>, grid, dim3(256), 0, stream, (const bf16*)qkv, ld_qkv,
+                     (const bf16*)kcache, (const bf16*)vcache, (const bf16*)rd, ld_rd, r_w_bias, r_r_bias, klen,
+                     active, (bf16*)out, ld_o, H, Lmax, scale);
+    else
+        return -22;
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lmax, hipStream_t stream) {
+    if (B <= 0) return 0;
+    COMMU_LAUNCH(klen_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, klen, advance, B, Lmax);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}

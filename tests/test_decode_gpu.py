@@ -142,3 +142,44 @@ def test_decode_loop_vs_reference_trace(golden_dir, tag):
             near = [float((torch.cumsum(p, 0) - u).abs().min()) for u, t, p in (d for d in drawn if len(d) == 3)]
             assert min(near) < 2e-2, (first, min(near))
             assert first > 12
+
+
+@pytest.mark.parametrize("tags", [("greedy8", "greedy5"), ("sample8", "sample4x")])
+def test_batched_kv_cache_decode_vs_reference_trace(golden_dir, tags):
+    """Several sequences decoded IN PARALLEL (K/V cache, ragged lengths, per-sequence forcing state) must each
+    reproduce the reference's sequential trace."""
+    from commu_amd.generate import BatchedGenerator
+    z = load(golden_dir, "g6_decode.npz")
+    model = _build(golden_dir, z, z[f"{tags[0]}_bias"])
+    assert np.array_equal(z[f"{tags[0]}_bias"], z[f"{tags[1]}_bias"])
+    temp, _, top_k, _ = z[f"{tags[0]}_cfg"]
+    datas, srcs, glen = [], [], 0
+    for tag in tags:
+        t, nm, k, gl = z[f"{tag}_cfg"]
+        assert t == temp
+        glen = max(glen, int(gl))
+        datas.append(types.SimpleNamespace(num_measures=float(nm), chord_token_components={
+            "chord_token": z[f"{tag}_chord_token"].tolist(), "chord_position": z[f"{tag}_chord_position"].tolist()}))
+        it = iter(z[f"{tag}_uniforms"].tolist())
+        srcs.append(lambda it=it: next(it, 0.5))
+    gen = BatchedGenerator(model, torch.device(DEV), generation_length=glen)
+    gen.uniform_sources = srcs
+    gen.trace = [[] for _ in tags]
+    meta = z["encoded_meta"].tolist()
+    seqs, teachers = gen.generate([meta] * len(tags), datas, float(temp), int(top_k))
+    for b, tag in enumerate(tags):
+        ref = z[f"{tag}_seq"].tolist()
+        gl = int(z[f"{tag}_cfg"][3])
+        got = seqs[b]
+        ref_trace = [tuple(t) for t in z[f"{tag}_trace"].tolist()]
+        if float(temp) == 0:
+            # the shorter fixture stops after its own generation_length iterations
+            n = len(ref)
+            assert got[:n] == ref, tag
+            assert gen.trace[b][:len(ref_trace)] == ref_trace, tag
+        else:
+            n = min(len(got), len(ref))
+            first = next((i for i in range(n) if got[i] != ref[i]), None)
+            assert first is None or first > 12, (tag, first)
+            if first is None and len(got) == len(ref):
+                assert gen.trace[b] == ref_trace
