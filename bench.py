@@ -67,6 +67,51 @@ def cpu_baseline(args):
                       f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step)"}
 
 
+def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
+    """Second half of BASELINE.json's metric: autoregressive decode tokens/s -- B sequences in parallel,
+    K/V-cached decode step + temperature/top-k sampling (top_k 32, T 0.95), one host sync per step."""
+    from commu_amd.generate import DecodeState
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab
+    from commu_amd.train import build_model
+    cfg = get_cfg(num_layers=args.layers, num_heads=args.heads, units=args.d_model, inner_size=args.d_inner,
+                  tgt_length=1, mem_length=4146, dropout=0.0, attention_dropout=0.0, same_length=True)
+    model = build_model(cfg, BaseVocab(), dev, seed=1).eval()
+    with torch.no_grad():
+        st = DecodeState(model, B, 4224)
+        ctx = torch.randint(2, 729, (11, B), device=dev)
+        st.prefill(ctx)
+        if klen0 > 11:                  # synthetic long memory: random cache content, lengths set directly
+            st.kc.normal_(0, 0.5)
+            st.vc.normal_(0, 0.5)
+            st.klen.fill_(klen0)
+        if graph:
+            st.capture(0.95, 32)
+        tok = torch.randint(2, 729, (B,), device=dev)
+        ones = torch.ones(B, dtype=torch.uint8, device=dev)
+        uni = torch.rand(B, device=dev)
+
+        def one():
+            if graph:
+                st.g_tok.copy_(tok)
+                st.g_uni.copy_(uni)
+                st.graph.replay()
+                return st.g_out.cpu()
+            st.step(tok, ones, ones)
+            from commu_amd import ops
+            return ops.sample_topk(st.logits, 0.95, 32, uniforms=uni, active=ones).cpu()
+        for _ in range(8):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"tokens_per_s": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4), "sequences": B,
+            "klen_start": klen0, "steps": steps, "hipgraph": bool(graph)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +127,7 @@ def main():
     ap.add_argument("--batch-chunk", type=int, default=1)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +170,7 @@ def main():
     if world > 1:
         dist.barrier()
     prof_names = ["commu_relattn_bwd", "commu_relattn_fwd", "commu_gemm_nt_bf16", "commu_gemm_tn_bf16"]
+    # (4 event pairs per entry-point call: ~1 us each on the host, < 2% of a step)
     _lib.profile_start(prof_names)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -179,6 +226,13 @@ def main():
                      "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
                      "time_share": {k: round(tot[k] / (1e3 * elapsed), 4) for k in tot}},
     }
+    if world == 1 and not args.no_decode:
+        del trainer, model
+        torch.cuda.empty_cache()
+        out["decode"] = {"metric": "autoregressive decode tokens/sec (64 sequences in parallel, K/V cache, "
+                                   "top-k 32 / T 0.95 sampling, 1 host sync per step)",
+                         "short_memory": decode_bench(dev, args, 11), "long_memory": decode_bench(dev, args, 1000),
+                         "long_memory_no_graph": decode_bench(dev, args, 1000, steps=64, graph=False)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

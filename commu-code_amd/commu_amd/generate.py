@@ -65,6 +65,35 @@ class DecodeState:
             self.vc[i, :, :T0].copy_(kv[:, :, 2 * HD:].transpose(0, 1))
         self.klen.fill_(T0)
 
+    # ---- hipGraph-captured step: the ~60 launches of one decode step + the sampling kernel replayed as one
+    # graph from static input buffers (launch-bound otherwise: each kernel runs for only a few microseconds)
+    def capture(self, temperature: float, top_k: int):
+        dev = self.klen.device
+        B = self.B
+        self.g_tok = torch.zeros(B, dtype=torch.long, device=dev)
+        self.g_active = torch.ones(B, dtype=torch.uint8, device=dev)
+        self.g_keep = torch.ones(B, dtype=torch.uint8, device=dev)
+        self.g_draw = torch.ones(B, dtype=torch.uint8, device=dev)
+        self.g_uni = torch.full((B,), 0.5, device=dev)
+        self.g_wrong = torch.zeros(B, 729, dtype=torch.uint8, device=dev)
+        self.g_out = torch.zeros(B, dtype=torch.int32, device=dev)
+        klen0 = self.klen.clone()
+
+        def body():
+            self.step(self.g_tok, self.g_active, self.g_keep)
+            ops.sample_topk(self.logits, temperature, top_k, wrong=self.g_wrong, uniforms=self.g_uni,
+                            active=self.g_draw, token=self.g_out)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()                                   # warm-up (allocations) outside capture
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+        self.klen.copy_(klen0)                       # warm-up / capture advanced the lengths
+        return self.graph
+
     def step(self, tokens: torch.Tensor, active: Optional[torch.Tensor], keep: torch.Tensor, want_logits=True):
         """One decode step for the sequences with active[b] != 0; klen advances where keep[b] != 0.
         tokens int64 [B]; active/keep uint8 [B].  Returns the fp32 logits buffer [B, 768] (rows of inactive
