@@ -42,8 +42,9 @@ class DecodeState:
         dev = fl["dev"]
         self.model, self.B, self.Lmax = model, B, Lmax
         L, HD, D = model.n_layer, model.n_head * model.d_head, model.d_model
-        self.kc = torch.zeros(L, B, Lmax, HD, device=dev, dtype=BF16)
-        self.vc = torch.zeros(L, B, Lmax, HD, device=dev, dtype=BF16)
+        H, DH = model.n_head, model.d_head
+        self.kc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)      # head-major: contiguous per (b, h)
+        self.vc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)
         self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
         pd = ops.posemb(model.pos_emb.inv_freq, Lmax, D)
         self.rd = [ops.gemm_nt(pd, model._weights(i)["r"]) for i in range(L)]
@@ -58,11 +59,11 @@ class DecodeState:
         T0, B = ctx.shape
         assert B == self.B
         _, _, qkvs = m._run_forward(ctx, None, None, None, need_grad=False, want_logits=True, want_kv=True)
-        HD = m.n_head * m.d_head
+        H, DH = m.n_head, m.d_head
         for i, qkv in enumerate(qkvs):
-            kv = qkv.view(T0, B, 3 * HD)
-            self.kc[i, :, :T0].copy_(kv[:, :, HD:2 * HD].transpose(0, 1))
-            self.vc[i, :, :T0].copy_(kv[:, :, 2 * HD:].transpose(0, 1))
+            kv = qkv.view(T0, B, 3, H, DH)
+            self.kc[i, :, :, :T0].copy_(kv[:, :, 1].permute(1, 2, 0, 3))
+            self.vc[i, :, :, :T0].copy_(kv[:, :, 2].permute(1, 2, 0, 3))
         self.klen.fill_(T0)
 
     # ---- hipGraph-captured step: the ~60 launches of one decode step + the sampling kernel replayed as one
@@ -109,7 +110,7 @@ class DecodeState:
             lay = m.layers[i]
             ops.gemm_nt(h, w["qkv"], out=self.qkv)
             call("commu_decode_kv_append", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
-                 _p(self.klen), _p(active), B, self.Lmax, HD, _s())
+                 _p(self.klen), _p(active), B, self.Lmax, H, HD, _s())
             call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
                  _p(self.rd[i]), self.rd[i].stride(0), _p(m.r_w_bias), _p(m.r_r_bias), _p(self.klen), _p(active),
                  _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, _s())

@@ -4,7 +4,7 @@
 // (commu/midi_generator/midi_inferrer.py:199-207, commu/model/model.py:606-628).  The reference
 // keeps the per-layer hidden states ("mems") and re-projects K and V of the WHOLE memory on every
 // step (model.py:283-288); with fixed weights the projections are identical each time, so they are
-// cached instead ([B][Lmax][H*DH] per layer, batch-major, bf16) and a step reads each cached row
+// cached instead ([B][H][Lmax][DH] per layer, bf16) and a step reads each cached row
 // once: HBM-bound.  Sequences are independent and RAGGED: klen[b] is the number of valid rows of
 // sequence b; the new token has position klen[b] and attends to rows 0..klen[b] with distance
 // d = klen[b] - j.  A step whose result the reference discards (quirk Q3) or a sequence that is not
@@ -17,63 +17,80 @@
 
 namespace {
 
+// caches are head-major: [B][H][Lmax][DH], so the rows one workgroup streams are contiguous
 __global__ void kv_append_kernel(const bf16* __restrict__ qkv, int ld_qkv, bf16* __restrict__ kc,
                                  bf16* __restrict__ vc, const int* __restrict__ klen,
-                                 const unsigned char* __restrict__ active, int B, int Lmax, int HD) {
+                                 const unsigned char* __restrict__ active, int B, int Lmax, int H, int DH) {
     const int b = blockIdx.x;
     if (active != nullptr && !active[b]) return;
     const int pos = klen[b];
     if (pos >= Lmax) return;
+    const int HD = H * DH;
     const bf16* src = qkv + (size_t)b * ld_qkv;
-    bf16* kd = kc + ((size_t)b * Lmax + pos) * HD;
-    bf16* vd = vc + ((size_t)b * Lmax + pos) * HD;
     for (int c = threadIdx.x * 8; c < HD; c += blockDim.x * 8) {
-        st_bf16x8(kd + c, ld_bf16x8(src + HD + c));
-        st_bf16x8(vd + c, ld_bf16x8(src + 2 * HD + c));
+        const int h = c / DH, f = c - h * DH;
+        const size_t off = (((size_t)b * H + h) * Lmax + pos) * DH + f;
+        st_bf16x8(kc + off, ld_bf16x8(src + HD + c));
+        st_bf16x8(vc + off, ld_bf16x8(src + 2 * HD + c));
     }
 }
 
 constexpr int DEC_MAXK = 4224;      // >= 4146 + 1 (memory_length of the inference config) rounded up
 
+// sum over the 8 lanes that share (lane >> 3): xor 1, xor 2 (quad_perm), then mirror within 8
+__device__ __forceinline__ float oct_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    return v;
+}
+
+// one workgroup per (b, h).  Both phases stream 16 bytes per lane: a wave instruction covers
+// 64/LPR consecutive cache rows (LPR = DH/8 lanes per row), fully coalesced.
 template <int DH>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const bf16* __restrict__ qkv, int ld_qkv, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
     const bf16* __restrict__ rd, int ld_rd, const float* __restrict__ u, const float* __restrict__ vb,
     const int* __restrict__ klen, const unsigned char* __restrict__ active, bf16* __restrict__ out, int ld_o,
     int H, int Lmax, float scale) {
+    constexpr int LPR = DH / 8;            // lanes per row (8 for DH 64, 4 for DH 32)
+    constexpr int RPW = 64 / LPR;          // rows per wave instruction
     __shared__ float sS[DEC_MAXK];
-    __shared__ float sQu[DH], sQv[DH];
     __shared__ float red[8];
-    __shared__ float sO[4][DH];
+    __shared__ float sO[4][RPW][DH];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     if (active != nullptr && !active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int sub = lane % LPR, rowl = lane / LPR;
     const int n = min(klen[b] + 1, Lmax);              // keys 0..klen[b] (the new token included)
-    const int HD = H * DH;
-    if (tid < DH) {
-        const float q = bf2f(qkv[(size_t)b * ld_qkv + h * DH + tid]);
-        sQu[tid] = q + u[h * DH + tid];
-        sQv[tid] = q + vb[h * DH + tid];
+    float qu[8], qv[8];
+    {
+        const bf16x8 q8 = ld_bf16x8(qkv + (size_t)b * ld_qkv + h * DH + 8 * sub);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float q = bf2f(q8[e]);
+            qu[e] = (q + u[h * DH + 8 * sub + e]) * scale;
+            qv[e] = (q + vb[h * DH + 8 * sub + e]) * scale;
+        }
     }
-    __syncthreads();
-    const bf16* kb = kc + (size_t)b * Lmax * HD + h * DH;
-    const bf16* vbp = vc + (size_t)b * Lmax * HD + h * DH;
-    // ---- scores: one key per thread
+    const bf16* kb = kc + ((size_t)b * H + h) * Lmax * DH + 8 * sub;
+    const bf16* vbp = vc + ((size_t)b * H + h) * Lmax * DH + 8 * sub;
+    const bf16* rb = rd + h * DH + 8 * sub;
+    // ---- scores: RPW keys per wave instruction
     float mx = -3.0e38f;
-    for (int j = tid; j < n; j += 256) {
-        const int d = (n - 1) - j;
-        const bf16* kr = kb + (size_t)j * HD;
-        const bf16* rr = rd + (size_t)d * ld_rd + h * DH;
+    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW) {
+        const int j = j0 + rowl;
+        const int jc = min(j, n - 1);
+        const bf16x8 kk = ld_bf16x8(kb + (size_t)jc * DH);
+        const bf16x8 r8 = ld_bf16x8(rb + (size_t)((n - 1) - jc) * ld_rd);
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < DH; c += 8) {
-            const bf16x8 kk = ld_bf16x8(kr + c), r8 = ld_bf16x8(rr + c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += sQu[c + e] * bf2f(kk[e]) + sQv[c + e] * bf2f(r8[e]);
+        for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kk[e]) + qv[e] * bf2f(r8[e]);
+        s = (LPR == 8) ? oct_sum(s) : (s + dpp_f<0xB1>(s)) + dpp_f<0x4E>(s + dpp_f<0xB1>(s));
+        if (j < n) {
+            if (sub == 0) sS[j] = s;
+            mx = fmaxf(mx, s);
         }
-        s *= scale;
-        sS[j] = s;
-        mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
     if (lane == 0) red[w] = mx;
@@ -89,14 +106,26 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     if (lane == 0) red[4 + w] = sum;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    // ---- P.V: wave w takes keys w, w+4, ...; lane = feature (DH <= 64)
-    float acc = 0.f;
-    if (lane < DH) {
-        for (int j = w; j < n; j += 4) acc += sS[j] * bf2f(vbp[(size_t)j * HD + lane]);
-        sO[w][lane] = acc;
+    // ---- P.V: lane accumulates 8 features of the keys it visits
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW) {
+        const int j = j0 + rowl;
+        if (j < n) {
+            const float p = sS[j];
+            const bf16x8 v8 = ld_bf16x8(vbp + (size_t)j * DH);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p * bf2f(v8[e]);
+        }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sO[w][rowl][8 * sub + e] = acc[e];
     __syncthreads();
-    if (tid < DH) out[(size_t)b * ld_o + h * DH + tid] = f2bf((sO[0][tid] + sO[1][tid] + sO[2][tid] + sO[3][tid]) * inv);
+    if (tid < DH) {
+        float o = 0.f;
+        for (int ww = 0; ww < 4; ++ww)
+            for (int r = 0; r < RPW; ++r) o += sO[ww][r][tid];
+        out[(size_t)b * ld_o + h * DH + tid] = f2bf(o * inv);
+    }
 }
 
 __global__ void klen_advance_kernel(int* __restrict__ klen, const unsigned char* __restrict__ advance, int B,
@@ -108,11 +137,12 @@ __global__ void klen_advance_kernel(int* __restrict__ klen, const unsigned char*
 }  // namespace
 
 extern "C" int commu_decode_kv_append(const void* qkv, int ld_qkv, void* kcache, void* vcache, const int* klen,
-                                      const unsigned char* active, int B, int Lmax, int HD, hipStream_t stream) {
+                                      const unsigned char* active, int B, int Lmax, int H, int HD,
+                                      hipStream_t stream) {
     if (B <= 0) return 0;
-    if ((HD % 8) || (ld_qkv % 8)) return -22;
+    if ((HD % 8) || (ld_qkv % 8) || H <= 0 || (HD % H) || ((HD / H) % 8)) return -22;
     COMMU_LAUNCH(kv_append_kernel, dim3(B), dim3(64), 0, stream, (const bf16*)qkv, ld_qkv, (bf16*)kcache,
-                 (bf16*)vcache, klen, active, B, Lmax, HD);
+                 (bf16*)vcache, klen, active, B, Lmax, H, HD / H);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -163,10 +163,10 @@ int commu_sample_topk(float* logits, int ld, int nseq, int V, const unsigned cha
                       int* token, float* probs_out, int ldp, hipStream_t stream);
 
 /* ---- single-token decode step with a K/V cache (forward_generate with qlen 1, model.py:606-628, as
- * called by midi_inferrer.py:199-207).  Caches are bf16 [B][Lmax][H*DH] per layer; klen[b] = valid rows
+ * called by midi_inferrer.py:199-207).  Caches are bf16 [B][H][Lmax][DH] per layer; klen[b] = valid rows
  * of sequence b (ragged); the new token sits at row klen[b] and attends rows 0..klen[b]. */
 int commu_decode_kv_append(const void* qkv, int ld_qkv, void* kcache, void* vcache, const int* klen,
-                           const unsigned char* active, int B, int Lmax, int HD, hipStream_t stream);
+                           const unsigned char* active, int B, int Lmax, int H, int HD, hipStream_t stream);
 /* out[b, h*DH:(h+1)*DH] = softmax_j(((q+u).k_j + (q+v).Rd[klen[b]-j]) * scale) . v_j   (rd: [>= Lmax][ld_rd]) */
 int commu_decode_attn(const void* qkv, int ld_qkv, const void* kcache, const void* vcache, const void* rd,
                       int ld_rd, const float* r_w_bias, const float* r_r_bias, const int* klen,
