@@ -58,6 +58,28 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float):
+    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests): rows 2r and 2r+1
+    share the hash word of (r, j) -- low / high 16 bits -- compared with round(p * 65536)."""
+    thr = max(1, int(p * 65536.0 + 0.5)) if p > 0 else 0
+    out = torch.empty(B, H, T, K, dtype=torch.bool)
+    rows = torch.arange(T, dtype=torch.int64)
+    cols = torch.arange(K, dtype=torch.int64)
+    idx = (rows[:, None] >> 1) * K + cols[None, :]
+    for b in range(B):
+        for h in range(H):
+            sbh = (seed + (b * H + h) * 0x9E3779B1) & 0xFFFFFFFF
+            x = (idx + sbh) & 0xFFFFFFFF
+            x = x ^ (x >> 16)
+            x = (x * 0x7feb352d) & 0xFFFFFFFF
+            x = x ^ (x >> 15)
+            x = (x * 0x846ca68b) & 0xFFFFFFFF
+            x = x ^ (x >> 16)
+            half = (x >> (16 * (rows[:, None] & 1))) & 0xFFFF
+            out[b, h] = half >= thr
+    return out, 1.0 - thr / 65536.0
+
+
 def _rowmajor2d(t: torch.Tensor, name: str):
     if t.dim() != 2 or t.stride(1) != 1:
         raise ValueError(f"{name}: need a 2-D tensor with unit column stride, got {tuple(t.shape)} / {t.stride()}")
@@ -330,18 +352,17 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     e.ld_dqkv, e.ld_dsk = dk.stride(0), ld_dsk
     assert dv.stride(0) == dk.stride(0)
     call("commu_relattn_bwd", C.byref(d), C.byref(e), _s())
-    # BD part of dq and dRd: two GEMMs per head over dS-by-distance
+    # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
     rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
     c2 = d.scale * 1.4426950408889634
-    ns = tn_slices(T * B, ld_dsk, DH)
-    slabs = torch.empty(ns * ld_dsk * DH, device=dev, dtype=F32)
-    tmp = torch.empty(ld_dsk, DH, device=dev, dtype=F32)
-    for h in range(H):
-        sl = slice(h * DH, (h + 1) * DH)
-        gemm_nt(dsk[h], rdt[0, h], out=dq[:, sl], resid=dq_ac[:, sl])
-        gemm_tn_raw(dsk[h], qv2[:, sl], slabs, ns)
-        reduce_slabs(tmp, slabs, ld_dsk * DH, ns, ld_dsk * DH, False, 1.0 / c2)
-        drd[:, sl].copy_(tmp[:K])
+    TB = T * B
+    call("commu_gemm_nt_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(rdt), ld_dsk, DH * ld_dsk, _p(dq), dq.stride(0),
+         DH, TB, DH, ld_dsk, _p(dq_ac), HD, DH, EPI_RESID, H, _s())
+    ns = tn_slices(TB, ld_dsk, DH * H)
+    slabs = torch.empty(H * ns * ld_dsk * DH, device=dev, dtype=F32)
+    call("commu_gemm_tn_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(qv2), HD, DH, _p(slabs), DH, ld_dsk * DH, TB,
+         ld_dsk, DH, ns, H, _s())
+    call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, ns, ld_dsk * DH, H, 0, 1.0 / c2, _s())
     # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)
     ca = torch.zeros(HD, device=dev, dtype=F32)
     colsum(du_part, ca)

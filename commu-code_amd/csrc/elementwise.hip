@@ -130,16 +130,31 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     for (int c = 0; c < LN_MAXC; ++c) {
         const int col = lane * 8 + 512 * c;
         if (col < D) {
-            bf16x8 o, od;
+            const f32x4 g0 = *(const f32x4*)(gamma + col), g1 = *(const f32x4*)(gamma + col + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + col), b1 = *(const f32x4*)(beta + col + 4);
+            bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = (x[c][e] - mu) * rs * gamma[col + e] + beta[col + e];
-                o[e] = f2bf(v);
-                if (ydrop != nullptr)
-                    od[e] = f2bf(drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr) ? v * drop_scale : 0.f);
+            for (int e = 0; e < 4; ++e) {
+                x[c][e] = (x[c][e] - mu) * rs * g0[e] + b0[e];
+                x[c][4 + e] = (x[c][4 + e] - mu) * rs * g1[e] + b1[e];
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(x[c][e]);
             st_bf16x8(y + (size_t)row * ldy + col, o);
-            if (ydrop != nullptr) st_bf16x8(ydrop + (size_t)row * ldyd + col, od);
+        }
+    }
+    if (ydrop != nullptr) {
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int col = lane * 8 + 512 * c;
+            if (col < D) {
+                bf16x8 od;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    od[e] = f2bf(drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr)
+                                     ? x[c][e] * drop_scale : 0.f);
+                st_bf16x8(ydrop + (size_t)row * ldyd + col, od);
+            }
         }
     }
 }

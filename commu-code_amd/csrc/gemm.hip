@@ -21,13 +21,19 @@ constexpr int BM = 128, BN = 128, BK = 32;
 // group ({0-3,12-15,20-27}, ...) touches 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int swz64(int row) { return ((row >> 3) & 1) * 3; }
 
-template <bool OUT_F32>
+struct GemmBatch {          // element strides between consecutive batch entries (blockIdx.y)
+    long long a, b, c, r;
+};
+
+// NBW = 16-column blocks per wave: 4 -> 128-wide tile, 2 -> 64-wide tile (per-head GEMMs, N = d_head)
+template <bool OUT_F32, int NBW>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
     void* __restrict__ Cv, int ldc, int M, int N, int K,
     const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr,
     const bf16* __restrict__ rmask, int ldm, int flags, int tiles_n, unsigned drop_seed, unsigned drop_thr,
-    float drop_scale, float mask_scale) {
+    float drop_scale, float mask_scale, GemmBatch bs) {
+    constexpr int BN = 32 * NBW;
     __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
 
@@ -36,37 +42,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    A += (long long)blockIdx.y * bs.a;
+    B += (long long)blockIdx.y * bs.b;
+    if (resid != nullptr) resid += (long long)blockIdx.y * bs.r;
+    const long long coff = (long long)blockIdx.y * bs.c;
 
     const int lrow = tid >> 2, lch = tid & 3;
+    constexpr int NLB = BN / 64;          // B-tile rows per thread (64 rows per pass)
     const bf16* ap[2];
-    const bf16* bp[2];
+    const bf16* bp[NLB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = lrow + 64 * i;
-        ap[i] = A + (size_t)min(m0 + r, M - 1) * lda + lch * 8;
-        bp[i] = B + (size_t)min(n0 + r, N - 1) * ldb + lch * 8;
-    }
-    bf16x8 ra[2], rb[2];
+    for (int i = 0; i < 2; ++i) ap[i] = A + (size_t)min(m0 + lrow + 64 * i, M - 1) * lda + lch * 8;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) bp[i] = B + (size_t)min(n0 + lrow + 64 * i, N - 1) * ldb + lch * 8;
+    bf16x8 ra[2], rb[NLB];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ra[i] = ld_bf16x8(ap[i] + kt * BK);
-            rb[i] = ld_bf16x8(bp[i] + kt * BK);
-        }
+        for (int i = 0; i < 2; ++i) ra[i] = ld_bf16x8(ap[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) rb[i] = ld_bf16x8(bp[i] + kt * BK);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = lrow + 64 * i;
-            const int off = r * BK + ((lch ^ swz64(r)) << 3);
-            st_bf16x8(&sA[buf][off], ra[i]);
-            st_bf16x8(&sB[buf][off], rb[i]);
+            st_bf16x8(&sA[buf][r * BK + ((lch ^ swz64(r)) << 3)], ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int r = lrow + 64 * i;
+            st_bf16x8(&sB[buf][r * BK + ((lch ^ swz64(r)) << 3)], rb[i]);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NBW][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NBW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -78,14 +89,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        bf16x8 af[4], bfr[4];
+        bf16x8 af[4], bfr[NBW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = ld_bf16x8(&sA[buf][(wr * 64 + 16 * i + r16) * BK + choff]);
-            bfr[i] = ld_bf16x8(&sB[buf][(wc * 64 + 16 * i + r16) * BK + choff]);
-        }
+        for (int i = 0; i < 4; ++i) af[i] = ld_bf16x8(&sA[buf][(wr * 64 + 16 * i + r16) * BK + choff]);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int i = 0; i < NBW; ++i) bfr[i] = ld_bf16x8(&sB[buf][(wc * 16 * NBW + 16 * i + r16) * BK + choff]);
+#pragma unroll
+        for (int ni = 0; ni < NBW; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(bfr[ni], af[mi], acc[ni][mi]);
         if (kt + 1 < nk) lstore(buf ^ 1);
@@ -98,8 +108,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
         const int m = m0 + wr * 64 + 16 * mi + r16;
         if (m >= M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wc * 64 + 16 * ni + 4 * g;
+        for (int ni = 0; ni < NBW; ++ni) {
+            const int n = n0 + wc * 16 * NBW + 16 * ni + 4 * g;
             if (n >= N) continue;
             f32x4 v = acc[ni][mi];
             const bool full = (n + 3 < N);
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
                     if (n + e < N) v[e] = (bf2f(rmask[(size_t)m * ldm + n + e]) > 0.f) ? v[e] * mask_scale : 0.f;
             }
             if (OUT_F32) {
-                float* C = (float*)Cv + (size_t)m * ldc + n;
+                float* C = (float*)Cv + coff + (size_t)m * ldc + n;
                 if (full) {
                     *(f32x4*)C = v;
                 } else {
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
                         if (n + e < N) C[e] = v[e];
                 }
             } else {
-                bf16* C = (bf16*)Cv + (size_t)m * ldc + n;
+                bf16* C = (bf16*)Cv + coff + (size_t)m * ldc + n;
                 if (full) {
                     bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     *(bf16x4*)C = o;
@@ -163,7 +173,8 @@ __device__ __forceinline__ int swz_tn(int row) { return (row & 3) | (((row >> 3)
 template <int NCOLS_B, int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
-    float* __restrict__ C, int ldc, size_t slab_stride, int Mtot, int N, int Kc, int m_per_slice) {
+    float* __restrict__ C, int ldc, size_t slab_stride, int Mtot, int N, int Kc, int m_per_slice, int nslices,
+    long long strideA, long long strideB) {
     // image A: [32][128] bf16, image B: [32][NCOLS_B]; double buffered
     __shared__ __attribute__((aligned(16))) bf16 sA[2][TM * 128];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][TM * NCOLS_B];
@@ -174,7 +185,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1, r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 128, k0 = blockIdx.y * NCOLS_B;
-    const int slice = blockIdx.z;
+    const int batch = blockIdx.z / nslices;
+    const int slice = blockIdx.z - batch * nslices;
+    A += (long long)batch * strideA;
+    B += (long long)batch * strideB;
     const int mbeg = slice * m_per_slice;
     const int mend = min(Mtot, mbeg + m_per_slice);
     const int nsteps = (mend - mbeg + TM - 1) / TM;
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
         if (st + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
-    float* Cs = C + (size_t)slice * slab_stride;
+    float* Cs = C + (size_t)blockIdx.z * slab_stride;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + wr * WN + 16 * ni + r16;
@@ -316,42 +330,78 @@ __global__ void reduce_slabs_kernel(float* __restrict__ dst, const float* __rest
     }
 }
 
+// dst[z][r*ldd + c] = (accumulate ? dst : 0) + alpha * sum_s src[(z*nslabs + s)*stride + r*cols + c]
+__global__ void reduce_slabs2d_kernel(float* __restrict__ dst, int ldd, long long dst_bs, const float* __restrict__ src,
+                                      int rows, int cols, int nslabs, size_t stride, int accumulate, float alpha) {
+    const int z = blockIdx.y;
+    const size_t n = (size_t)rows * cols;
+    const float* sp = src + (size_t)z * nslabs * stride;
+    float* dp = dst + (long long)z * dst_bs;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nslabs; ++k) s += sp[(size_t)k * stride + i];
+        const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+        float* o = dp + (size_t)r * ldd + c;
+        *o = (accumulate ? *o : 0.f) + alpha * s;
+    }
+}
+
 }  // namespace
+
+static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                          const float* bias, const void* resid, int ldr, const void* relu_mask, int ldm, int flags,
+                          unsigned drop_seed, float drop_p, float mask_scale, int batch, GemmBatch bs,
+                          hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (K <= 0 || (K % BK) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
+    const bool narrow = (N <= 64);
+    const int bn = narrow ? 64 : 128;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + bn - 1) / bn;
+    dim3 grid(tiles_m * tiles_n, batch);
+    const unsigned drop_thr = (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0);
+    const float drop_scale = 1.f / (1.f - drop_p);
+#define NT_LAUNCH(F32, NBW)                                                                                   \
+    COMMU_LAUNCH((gemm_nt_kernel<F32, NBW>), grid, dim3(256), 0, stream, (const bf16*)A, lda, (const bf16*)B, \
+                 ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags,     \
+                 tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs)
+    if (flags & COMMU_EPI_OUT_F32) {
+        if (narrow) NT_LAUNCH(true, 2); else NT_LAUNCH(true, 4);
+    } else {
+        if (narrow) NT_LAUNCH(false, 2); else NT_LAUNCH(false, 4);
+    }
+#undef NT_LAUNCH
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                                   int M, int N, int K, const float* bias, const void* resid, int ldr,
                                   const void* relu_mask, int ldm, int flags, unsigned drop_seed, float drop_p,
                                   float mask_scale, hipStream_t stream) {
-    if (M <= 0 || N <= 0) return 0;
-    if (K <= 0 || (K % BK) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n);
-    const unsigned drop_thr = (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0);
-    const float drop_scale = 1.f / (1.f - drop_p);
-    if (flags & COMMU_EPI_OUT_F32)
-        COMMU_LAUNCH(gemm_nt_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
-                           (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
-                           (const bf16*)relu_mask, ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale);
-    else
-        COMMU_LAUNCH(gemm_nt_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)A, lda,
-                           (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr,
-                           (const bf16*)relu_mask, ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale);
-    COMMU_LAUNCH_CHECK();
-    return 0;
+    return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, relu_mask, ldm, flags, drop_seed, drop_p,
+                          mask_scale, 1, GemmBatch{0, 0, 0, 0}, stream);
 }
 
-extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs,
-                                  int ldc, size_t slab_stride, int M, int N, int K, int nslices,
-                                  int mode, hipStream_t stream) {
-    if (N <= 0 || K <= 0 || nslices <= 0) return 0;
+extern "C" int commu_gemm_nt_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
+                                          long long strideB, void* C, int ldc, long long strideC, int M, int N,
+                                          int K, const void* resid, int ldr, long long strideR, int flags,
+                                          int batch, hipStream_t stream) {
+    return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, nullptr, resid, ldr, nullptr, 0, flags, 0u, 0.f, 1.f, batch,
+                          GemmBatch{strideA, strideB, strideC, strideR}, stream);
+}
+
+static int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc, size_t slab_stride,
+                          int M, int N, int K, int nslices, int mode, int batch, long long strideA, long long strideB,
+                          hipStream_t stream) {
+    if (N <= 0 || K <= 0 || nslices <= 0 || batch <= 0) return 0;
     if ((lda % 8) || (ldb % 8) || (ldc % 4) || (N % 8) || (K % 8)) return -22;
     int mps = (M + nslices - 1) / nslices;
     mps = ((mps + TM - 1) / TM) * TM;
     const bool narrow = (K <= 64);
-    dim3 grid((N + 127) / 128, narrow ? (K + 63) / 64 : (K + 127) / 128, nslices);
+    dim3 grid((N + 127) / 128, narrow ? (K + 63) / 64 : (K + 127) / 128, nslices * batch);
 #define TN_LAUNCH(NC, MD)                                                                          \
-    COMMU_LAUNCH((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,  \
-                       (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps)
+    COMMU_LAUNCH((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,        \
+                 (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps, nslices, strideA, strideB)
     if (narrow) {
         if (mode) TN_LAUNCH(64, 1); else TN_LAUNCH(64, 0);
     } else {
@@ -362,6 +412,19 @@ extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb
     return 0;
 }
 
+extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs,
+                                  int ldc, size_t slab_stride, int M, int N, int K, int nslices,
+                                  int mode, hipStream_t stream) {
+    return launch_gemm_tn(A, lda, B, ldb, slabs, ldc, slab_stride, M, N, K, nslices, mode, 1, 0, 0, stream);
+}
+
+/* batch entry z: slabs[(z*nslices + s)][n,k] */
+extern "C" int commu_gemm_tn_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
+                                          long long strideB, float* slabs, int ldc, size_t slab_stride, int M,
+                                          int N, int K, int nslices, int batch, hipStream_t stream) {
+    return launch_gemm_tn(A, lda, B, ldb, slabs, ldc, slab_stride, M, N, K, nslices, 1, batch, strideA, strideB, stream);
+}
+
 extern "C" int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs,
                                       size_t stride, int accumulate, float alpha, hipStream_t stream) {
     if (n == 0) return 0;
@@ -370,6 +433,18 @@ extern "C" int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, in
     if (blocks == 0) blocks = 1;
     COMMU_LAUNCH(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, n,
                        nslabs, stride, accumulate, alpha);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, const float* src, int rows,
+                                        int cols, int nslabs, size_t stride, int batch, int accumulate, float alpha,
+                                        hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
+    size_t blocks = ((size_t)rows * cols + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    COMMU_LAUNCH(reduce_slabs2d_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, stream, dst, ldd, dst_batch_stride,
+                 src, rows, cols, nslabs, stride, accumulate, alpha);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -51,7 +51,8 @@ struct AttnArgs {
     int T, M, B, H;
     int same_length, sshift;
     float scale;
-    unsigned drop_seed, drop_thr;   // attention-probability dropout (thr == 0: off)
+    unsigned drop_seed, drop_thr;   // attention-probability dropout: 16-bit threshold (0: off); rows 2r, 2r+1
+                                    // share the hash word mix32(seed_bh + r*K + j), low / high half
     float drop_scale;
 };
 
@@ -309,13 +310,17 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 pb;
+            unsigned hw[2] = {0u, 0u};
+            if (a.drop_thr) {          // one hash word per (row pair, column): 16 bits per element
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp)
+                    hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
+            }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
                 lpart[reg] += p;                               // the normaliser is the un-dropped sum
-                if (a.drop_thr)
-                    p = drop_keep(seed_bh, (unsigned)(iw_lo + 4 * g + reg) * (unsigned)K + (unsigned)(j0 + 16 * c + r16),
-                                  a.drop_thr) ? p * a.drop_scale : 0.f;
+                if (a.drop_thr) p = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? p * a.drop_scale : 0.f;
                 pb[reg] = f2bf(p);
             }
             *(bf16x4*)(myP + (16 * c + r16) * PT + 4 * g) = pb;       // P^T[kv][row]: rows 4g..4g+3
@@ -475,13 +480,17 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 db;
+            unsigned hw[2] = {0u, 0u};
+            if (a.drop_thr) {
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp)
+                    hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
+            }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);
                 float dpe = dp[c][reg];
-                if (a.drop_thr)
-                    dpe = drop_keep(seed_bh, (unsigned)(iw_lo + 4 * g + reg) * (unsigned)K + (unsigned)(j0 + 16 * c + r16),
-                                    a.drop_thr) ? dpe * a.drop_scale : 0.f;
+                if (a.drop_thr) dpe = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? dpe * a.drop_scale : 0.f;
                 const float ds = p * (dpe - dl[reg]) * a.scale;
                 s[c][reg] = ds;
                 db[reg] = f2bf(ds);
@@ -662,6 +671,13 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
                 qr1 = mfma16(qvf, frag<DH>(sR, pr1, 4 * ks + g), qr1);
             }
 #pragma unroll
+            unsigned hw[2] = {0u, 0u};
+            if (a.drop_thr) {
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp)
+                    hw[rp] = mix32(seed_bh + (unsigned)((i0 + 16 * rb + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(jw_lo + r16));
+            }
+#pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const float p0 = bperm(srcaddr[reg], qr0[reg]);
                 const float p1 = bperm(srcaddr[reg], qr1[reg]);
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
                 const float p = __builtin_amdgcn_exp2f(sc - sLse[ii]);
                 float pd = p, dpe = dp[reg];
                 if (a.drop_thr) {
-                    const bool keep = drop_keep(seed_bh, (unsigned)(i0 + ii) * (unsigned)K + (unsigned)(jw_lo + r16), a.drop_thr);
+                    const bool keep = ((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr;
                     pd = keep ? p * a.drop_scale : 0.f;
                     dpe = keep ? dpe * a.drop_scale : 0.f;
                 }
@@ -776,8 +792,9 @@ static void fill_common(AttnArgs& a, const commu_attn_desc* d) {
     a.T = d->T; a.M = d->M; a.B = d->B; a.H = d->H;
     a.same_length = d->same_length; a.sshift = d->sshift; a.scale = d->scale;
     a.drop_seed = d->drop_seed;
-    a.drop_thr = d->drop_p > 0.f ? (unsigned)((double)d->drop_p * 4294967296.0) : 0u;
-    a.drop_scale = 1.f / (1.f - d->drop_p);
+    a.drop_thr = d->drop_p > 0.f ? (unsigned)((double)d->drop_p * 65536.0 + 0.5) : 0u;
+    if (d->drop_p > 0.f && a.drop_thr == 0u) a.drop_thr = 1u;
+    a.drop_scale = 1.f / (1.f - (float)a.drop_thr / 65536.f);      // scale by the exact keep probability
     a.q = (const bf16*)d->q; a.k = (const bf16*)d->k; a.v = (const bf16*)d->v; a.rd = (const bf16*)d->rd;
 }
 

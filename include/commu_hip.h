@@ -41,10 +41,23 @@ int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, 
                        int K, const float* bias, const void* resid, int ldr, const void* relu_mask,
                        int ldm, int flags, unsigned drop_seed, float drop_p, float mask_scale,
                        hipStream_t stream);
+/* batched form: entry z uses A + z*strideA, B + z*strideB, C + z*strideC, resid + z*strideR (element
+ * strides); a 64-wide tile is used when N <= 64 (per-head GEMMs).  Epilogue flags: RESID, OUT_F32. */
+int commu_gemm_nt_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
+                               long long strideB, void* C, int ldc, long long strideC, int M, int N, int K,
+                               const void* resid, int ldr, long long strideR, int flags, int batch,
+                               hipStream_t stream);
 /* slabs[s][n,k] = sum_{m in slice s} A[m,n] * B[m,k]  (weight gradients dW = dY^T X).
  * mode 1: LDS transpose reads (ds_read_b64_tr_b16); mode 0: 16-bit gathers. */
 int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc,
                        size_t slab_stride, int M, int N, int K, int nslices, int mode, hipStream_t stream);
+/* batched form: slabs[(z*nslices + s)][n,k] for batch entry z */
+int commu_gemm_tn_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
+                               long long strideB, float* slabs, int ldc, size_t slab_stride, int M, int N, int K,
+                               int nslices, int batch, hipStream_t stream);
+/* dst[z][r*ldd + c] = (accumulate ? dst : 0) + alpha * sum_s src[(z*nslabs + s)*stride + r*cols + c] */
+int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, const float* src, int rows, int cols,
+                             int nslabs, size_t stride, int batch, int accumulate, float alpha, hipStream_t stream);
 /* dst[i] = (accumulate ? dst[i] : 0) + alpha * sum_s src[s*stride + i] */
 int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, size_t stride,
                            int accumulate, float alpha, hipStream_t stream);

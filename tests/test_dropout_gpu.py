@@ -91,13 +91,9 @@ def test_embed_posemb_layernorm_dropout_exact_mask():
 
 
 def attn_keep(seed, B, H, T, K, p):
+    """(keep mask, exact keep probability) of the attention kernels."""
     from commu_amd import ops
-    m = torch.empty(B, H, T, K, dtype=torch.bool)
-    for b in range(B):
-        for h in range(H):
-            sbh = (seed + (b * H + h) * 0x9E3779B1) & 0xFFFFFFFF
-            m[b, h] = ops.dropout_keep_mask(sbh, T * K, p).view(T, K)
-    return m
+    return ops.attn_dropout_keep_mask(seed, B, H, T, K, p)
 
 
 @pytest.mark.parametrize("case", [(64, 0, 2, 2, 64), (40, 24, 2, 2, 32), (130, 0, 1, 1, 64)])
@@ -109,14 +105,14 @@ def test_attention_dropout_fwd_bwd_exact_mask(case):
     qkv = bf(torch.randn(K * B, 3 * HD, generator=g) * 0.7)
     rd = bf(torch.randn(K, HD, generator=g) * 0.7)
     u, vb = torch.randn(HD, generator=g) * 0.3, torch.randn(HD, generator=g) * 0.3
-    keep = attn_keep(seed, B, H, T, K, p)
+    keep, pkeep = attn_keep(seed, B, H, T, K, p)
     leaf = qkv.float().requires_grad_(True)
     rdl, ul, vl = rd.float().requires_grad_(True), u.clone().requires_grad_(True), vb.clone().requires_grad_(True)
     r = rdl.view(K, H, DH).flip(0)
     S = X.rel_attention_scores(leaf[M * B:, :HD].reshape(T, B, H, DH), leaf[:, HD:2 * HD].reshape(K, B, H, DH), r,
                                ul.view(H, DH), vl.view(H, DH)) / math.sqrt(DH)
     S = S.masked_fill(X.attn_mask(T, M, B, None, False, M)[:, None], float("-inf"))
-    A = torch.softmax(S, 3) * keep / (1 - p)
+    A = torch.softmax(S, 3) * keep / pkeep
     ref = torch.einsum("bnij,jbnd->ibnd", A, leaf[:, 2 * HD:].reshape(K, B, H, DH)).reshape(T * B, HD)
     dout = bf(torch.randn(T * B, HD, generator=g))
     ref.backward(dout.float())
@@ -168,8 +164,8 @@ def test_model_train_mode_matches_oracle_with_same_masks(golden_dir):
             kind, li = site
             ss = ops.site_seed(seed, site_id[kind](li))
             if kind == "att":
-                keep = attn_keep(ss, x.shape[0], x.shape[1], x.shape[2], x.shape[3], p_att)
-                return x * keep / (1 - p_att)
+                keep, pkeep = attn_keep(ss, x.shape[0], x.shape[1], x.shape[2], x.shape[3], p_att)
+                return x * keep / pkeep
             if kind == "pos":                       # the kernel's table is indexed by distance = reversed rows
                 keep = ops.dropout_keep_mask(ss, x.numel(), p_drop).view(x.shape).flip(0)
                 return x * keep / (1 - p_drop)
