@@ -670,7 +670,6 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
                 qr0 = mfma16(qvf, frag<DH>(sR, pr0, 4 * ks + g), qr0);
                 qr1 = mfma16(qvf, frag<DH>(sR, pr1, 4 * ks + g), qr1);
             }
-#pragma unroll
             unsigned hw[2] = {0u, 0u};
             if (a.drop_thr) {
 #pragma unroll
