@@ -27,7 +27,8 @@ class AttnDesc(C.Structure):
 
 class AttnBwdDesc(C.Structure):
     _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
-                ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i)]
+                ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
+                ("du_rows", c_i)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
@@ -62,6 +63,7 @@ PROTOTYPES = {
     "commu_copy_bf16": [c_p, c_p, c_z, c_p],
     "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p],
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
+    "commu_attn_bwd_qrows": [c_i],
     "commu_attn_delta": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_sample_topk": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
@@ -71,7 +73,7 @@ PROTOTYPES = {
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version"}
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows"}
 
 _lib = None
 

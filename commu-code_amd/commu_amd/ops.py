@@ -335,7 +335,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     dev = q.device
     K = T + M
     HD = H * DH
-    QT = (T + 63) // 64
+    qrows = call("commu_attn_bwd_qrows", T)
+    QT = (T + qrows - 1) // qrows
     qu2, qv2 = qs
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
     call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
@@ -349,7 +350,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     e.qu2, e.qv2 = qu2.data_ptr(), qv2.data_ptr()
     e.dq_ac, e.dk, e.dv = dq_ac.data_ptr(), dk.data_ptr(), dv.data_ptr()
     e.dsk, e.du_part = dsk.data_ptr(), du_part.data_ptr()
-    e.ld_dqkv, e.ld_dsk = dk.stride(0), ld_dsk
+    e.ld_dqkv, e.ld_dsk, e.du_rows = dk.stride(0), ld_dsk, QT
     assert dv.stride(0) == dk.stride(0)
     call("commu_relattn_bwd", C.byref(d), C.byref(e), _s())
     # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads

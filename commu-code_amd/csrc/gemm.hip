@@ -12,10 +12,11 @@
 #include "common.cuh"
 #include "commu_hip.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 
 // 64-byte LDS rows (32 bf16): XOR the 16-byte chunk index so that each ds_read_b128 lane
 // group ({0-3,12-15,20-27}, ...) touches 16 distinct 16-byte slots of the 256-byte bank row.
@@ -26,19 +27,33 @@ struct GemmBatch {          // element strides between consecutive batch entries
 };
 
 // NBW = 16-column blocks per wave: 4 -> 128-wide tile, 2 -> 64-wide tile (per-head GEMMs, N = d_head)
-template <bool OUT_F32, int NBW>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
+// swizzle of the 16-byte chunk index for a row of BKT bf16 (64 or 128 bytes)
+template <int BKT>
+__device__ __forceinline__ int swzk(int row) { return BKT == 64 ? (row & 7) : swz64(row); }
+
+// Tile = (16*MBW*WM) x (16*NBW*WN): WM x WN waves, each MBW x NBW MFMA blocks.  Configurations:
+//   <4,4|2,2,2>: 128 x 128|64, 256 threads     <8,4,2,4>: 256 x 256, 512 threads (halves the bytes each
+//   CU loads per flop: the 128x128 tile is bound by the ~15 B/cycle/CU vector-load path, not by MFMA)
+// GLDS: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write); the LDS image
+// is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address instead.
+template <bool OUT_F32, int NBW, int BKT, int MBW = 4, int WM = 2, int WN = 2, bool GLDS = true>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
     void* __restrict__ Cv, int ldc, int M, int N, int K,
     const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr,
     const bf16* __restrict__ rmask, int ldm, int flags, int tiles_n, unsigned drop_seed, unsigned drop_thr,
     float drop_scale, float mask_scale, GemmBatch bs) {
-    constexpr int BN = 32 * NBW;
+    constexpr int BM = 16 * MBW * WM;
+    constexpr int BN = 16 * NBW * WN;
+    constexpr int BK = BKT;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row (4 or 8)
+    constexpr int RPP = NTHR / CPR;             // tile rows covered by one pass of all threads
     __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * BK];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * BK];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1, r16 = lane & 15, g = lane >> 4;
+    const int wr = w / WN, wc = w % WN, r16 = lane & 15, g = lane >> 4;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -47,65 +62,101 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     if (resid != nullptr) resid += (long long)blockIdx.y * bs.r;
     const long long coff = (long long)blockIdx.y * bs.c;
 
-    const int lrow = tid >> 2, lch = tid & 3;
-    constexpr int NLB = BN / 64;          // B-tile rows per thread (64 rows per pass)
-    const bf16* ap[2];
+    const int lrow = tid / CPR, lch = tid % CPR;
+    constexpr int NLA = BM / RPP;         // A-tile chunks per thread
+    constexpr int NLB = BN / RPP;         // B-tile chunks per thread
+    const bf16* ap[NLA];
     const bf16* bp[NLB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ap[i] = A + (size_t)min(m0 + lrow + 64 * i, M - 1) * lda + lch * 8;
+    for (int i = 0; i < NLA; ++i) ap[i] = A + (size_t)min(m0 + lrow + RPP * i, M - 1) * lda + lch * 8;
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) bp[i] = B + (size_t)min(n0 + lrow + 64 * i, N - 1) * ldb + lch * 8;
-    bf16x8 ra[2], rb[NLB];
+    for (int i = 0; i < NLB; ++i) bp[i] = B + (size_t)min(n0 + lrow + RPP * i, N - 1) * ldb + lch * 8;
+    bf16x8 ra[NLA], rb[NLB];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = ld_bf16x8(ap[i] + kt * BK);
+        for (int i = 0; i < NLA; ++i) ra[i] = ld_bf16x8(ap[i] + kt * BK);
 #pragma unroll
         for (int i = 0; i < NLB; ++i) rb[i] = ld_bf16x8(bp[i] + kt * BK);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = lrow + 64 * i;
-            st_bf16x8(&sA[buf][r * BK + ((lch ^ swz64(r)) << 3)], ra[i]);
+        for (int i = 0; i < NLA; ++i) {
+            const int r = lrow + RPP * i;
+            st_bf16x8(&sA[buf][r * BK + ((lch ^ swzk<BKT>(r)) << 3)], ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
-            const int r = lrow + 64 * i;
-            st_bf16x8(&sB[buf][r * BK + ((lch ^ swz64(r)) << 3)], rb[i]);
+            const int r = lrow + RPP * i;
+            st_bf16x8(&sB[buf][r * BK + ((lch ^ swzk<BKT>(r)) << 3)], rb[i]);
         }
     };
 
-    f32x4 acc[NBW][4];
+    f32x4 acc[NBW][MBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    gload(0);
-    lstore(0);
+    // ---- LDS-DMA staging: chunk q = tid + NTHR*i of a tile lands at LDS byte 16*q; it holds tile row q / CPR,
+    // logical chunk (q % CPR) ^ swz(row)
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const bf16* gpa[NLA];
+    const bf16* gpb[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int q = tid + NTHR * i, r = q / CPR, pc = q % CPR;
+        gpa[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((pc ^ swzk<BKT>(r)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int q = tid + NTHR * i, r = q / CPR, pc = q % CPR;
+        gpb[i] = B + (size_t)min(n0 + r, N - 1) * ldb + ((pc ^ swzk<BKT>(r)) << 3);
+    }
+    auto glds = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gpa[i] + kt * BK),
+                                             (LDS_AS void*)(&sA[buf][(wbase + NTHR * i) * 8]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gpb[i] + kt * BK),
+                                             (LDS_AS void*)(&sB[buf][(wbase + NTHR * i) * 8]), 16, 0, 0);
+    };
+    if (GLDS) {
+        glds(0, 0);
+    } else {
+        gload(0);
+        lstore(0);
+    }
     __syncthreads();
-    const int choff = (g ^ swz64(r16)) << 3;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        bf16x8 af[4], bfr[NBW];
+        if (kt + 1 < nk) {
+            if (GLDS) glds(kt + 1, buf ^ 1); else gload(kt + 1);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = ld_bf16x8(&sA[buf][(wr * 64 + 16 * i + r16) * BK + choff]);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            // (all fragment rows are r16 + a multiple of 16, so the swizzle term depends on r16 only)
+            const int choff = ((4 * ks + g) ^ swzk<BKT>(r16)) << 3;
+            bf16x8 af[MBW], bfr[NBW];
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) bfr[i] = ld_bf16x8(&sB[buf][(wc * 16 * NBW + 16 * i + r16) * BK + choff]);
+            for (int i = 0; i < MBW; ++i) af[i] = ld_bf16x8(&sA[buf][(wr * 16 * MBW + 16 * i + r16) * BK + choff]);
 #pragma unroll
-        for (int ni = 0; ni < NBW; ++ni)
+            for (int i = 0; i < NBW; ++i) bfr[i] = ld_bf16x8(&sB[buf][(wc * 16 * NBW + 16 * i + r16) * BK + choff]);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(bfr[ni], af[mi], acc[ni][mi]);
-        if (kt + 1 < nk) lstore(buf ^ 1);
+            for (int ni = 0; ni < NBW; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MBW; ++mi) acc[ni][mi] = mfma16(bfr[ni], af[mi], acc[ni][mi]);
+        }
+        if (!GLDS && kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: lane holds C[m = .. + r16][n = .. + 4g + reg]
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wr * 64 + 16 * mi + r16;
+    for (int mi = 0; mi < MBW; ++mi) {
+        const int m = m0 + wr * 16 * MBW + 16 * mi + r16;
         if (m >= M) continue;
 #pragma unroll
         for (int ni = 0; ni < NBW; ++ni) {
@@ -353,21 +404,34 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
                           unsigned drop_seed, float drop_p, float mask_scale, int batch, GemmBatch bs,
                           hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    if (K <= 0 || (K % BK) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
+    if (K <= 0 || (K % 32) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
     const bool narrow = (N <= 64);
-    const int bn = narrow ? 64 : 128;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + bn - 1) / bn;
+    const bool big = !narrow && M >= 2048 && N >= 256 && (N % 256 == 0 || N >= 1024) && !getenv("COMMU_GEMM_SMALL");
+    const int bn = narrow ? 64 : (big ? 256 : 128), bm = big ? 256 : 128;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     dim3 grid(tiles_m * tiles_n, batch);
     const unsigned drop_thr = (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0);
     const float drop_scale = 1.f / (1.f - drop_p);
-#define NT_LAUNCH(F32, NBW)                                                                                   \
-    COMMU_LAUNCH((gemm_nt_kernel<F32, NBW>), grid, dim3(256), 0, stream, (const bf16*)A, lda, (const bf16*)B, \
-                 ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags,     \
+#define NT_LAUNCH(F32, NBW, BKT)                                                                                   \
+    COMMU_LAUNCH((gemm_nt_kernel<F32, NBW, BKT>), grid, dim3(256), 0, stream, (const bf16*)A, lda, (const bf16*)B, \
+                 ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags,          \
                  tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs)
-    if (flags & COMMU_EPI_OUT_F32) {
-        if (narrow) NT_LAUNCH(true, 2); else NT_LAUNCH(true, 4);
+    const bool k64 = (K % 64 == 0) && !getenv("COMMU_GEMM_BK32");
+    if (big) {
+        if (flags & COMMU_EPI_OUT_F32)
+            COMMU_LAUNCH((gemm_nt_kernel<true, 4, 32, 8, 2, 4>), grid, dim3(512), 0, stream, (const bf16*)A, lda,
+                         (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask,
+                         ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs);
+        else
+            COMMU_LAUNCH((gemm_nt_kernel<false, 4, 32, 8, 2, 4>), grid, dim3(512), 0, stream, (const bf16*)A, lda,
+                         (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask,
+                         ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs);
+    } else if (flags & COMMU_EPI_OUT_F32) {
+        if (narrow) { if (k64) NT_LAUNCH(true, 2, 64); else NT_LAUNCH(true, 2, 32); }
+        else { if (k64) NT_LAUNCH(true, 4, 64); else NT_LAUNCH(true, 4, 32); }
     } else {
-        if (narrow) NT_LAUNCH(false, 2); else NT_LAUNCH(false, 4);
+        if (narrow) { if (k64) NT_LAUNCH(false, 2, 64); else NT_LAUNCH(false, 2, 32); }
+        else { if (k64) NT_LAUNCH(false, 4, 64); else NT_LAUNCH(false, 4, 32); }
     }
 #undef NT_LAUNCH
     COMMU_LAUNCH_CHECK();

@@ -24,6 +24,7 @@
 // dv), attn_delta, transpose_heads.
 #include "common.cuh"
 #include "commu_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -109,13 +110,13 @@ __device__ __forceinline__ float bperm(int addr, float v) {
 __device__ __forceinline__ bool is_masked(int i, int j, int M, int same_length, int sshift, bool rst) {
     return (j > i + M) || (same_length && j <= i - sshift) || (rst && j < M);
 }
-// kv tile range visible from query rows [i0, i0+63]
-__device__ __forceinline__ void kv_range(const AttnArgs& a, int i0, bool rst, int& jt_lo, int& jt_hi) {
+// kv tile range visible from query rows [i0, i0+qrows-1]
+__device__ __forceinline__ void kv_range(const AttnArgs& a, int i0, int qrows, bool rst, int& jt_lo, int& jt_hi) {
     const int K = a.T + a.M;
     int jlo = rst ? a.M : 0;
     if (a.same_length) jlo = max(jlo, i0 - a.sshift + 1);
     jlo = max(jlo, 0);
-    const int jhi = min(K - 1, i0 + 63 + a.M);
+    const int jhi = min(K - 1, i0 + qrows - 1 + a.M);
     jt_lo = jlo >> 6;
     jt_hi = jhi >> 6;
 }
@@ -132,48 +133,57 @@ __device__ __forceinline__ srd_t make_srd(const void* p, size_t bytes) {
 __device__ __forceinline__ bf16x8 buf_ld(srd_t r, unsigned byte_off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
-template <int ROWS, int COLS>
+template <int ROWS, int COLS, int NTHR = 256>
 struct Stager {
     static constexpr int CH = COLS / 8;
-    static constexpr int N = (ROWS * CH) / 256;
-    static_assert((ROWS * CH) % 256 == 0, "tile must be a multiple of 256 16-byte chunks");
+    static constexpr int N = (ROWS * CH + NTHR - 1) / NTHR;
+    static constexpr bool FULL = (ROWS * CH) % NTHR == 0;      // every thread owns N chunks
     bf16x8 reg[N];
     unsigned goff[N];      // byte offset of this thread's chunk n inside the tile (global side)
     unsigned loff[N];      // swizzled byte offset inside the LDS tile
+    bool own;              // (partial tiles only) this thread has a chunk in the last pass
     __device__ __forceinline__ void init(unsigned row_stride_bytes, int tid) {
+        own = true;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
-            const int i = tid + 256 * n, r = i / CH, c = i % CH;
+            const int i = tid + NTHR * n, r = i / CH, c = i % CH;
             goff[n] = (unsigned)r * row_stride_bytes + (unsigned)c * 16u;
             loff[n] = (unsigned)(r * COLS + ((c ^ (swz<COLS>(r) & (CH - 1))) << 3)) * 2u;
+            if (!FULL && n == N - 1) own = i < ROWS * CH;
         }
     }
     __device__ __forceinline__ void load(srd_t srd, unsigned tile_off) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) reg[n] = buf_ld(srd, goff[n] + tile_off);
+        for (int n = 0; n < N; ++n)      // a thread without a chunk reads far out of range (returns zero, no branch)
+            reg[n] = buf_ld(srd, (FULL || n < N - 1 || own) ? goff[n] + tile_off : 0xFFFFFFF0u);
     }
     __device__ __forceinline__ void store(bf16* dst) const {
 #pragma unroll
-        for (int n = 0; n < N; ++n) *(bf16x8*)((char*)dst + loff[n]) = reg[n];
+        for (int n = 0; n < N; ++n)
+            if (FULL || n < N - 1 || own) *(bf16x8*)((char*)dst + loff[n]) = reg[n];
     }
 };
 
 // band row x (0..127) of tile number t lives in a ring of two 64-row halves: half (x>>6) of tile t
 // sits at physical half ((x>>6) + t) & 1, so the half shared by consecutive tiles is never moved.
-__device__ __forceinline__ int ring_row(int x, int t) { return ((((x >> 6) + t) & 1) << 6) + (x & 63); }
+// NCH chunks of 64 rows; STEP = +1 when the band moves up by 64 per tile (kv-stationary loop over query
+// tiles), NCH-1 (= -1 mod NCH) when it moves down (q-stationary loops over key tiles).
+template <int NCH, int STEP>
+__device__ __forceinline__ int ring_row(int x, int t) { return ((((x >> 6) + STEP * t) % NCH) << 6) + (x & 63); }
 
 // =============================================================================================
-template <int DH>
-__global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
+    constexpr int QROWS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // query rows per workgroup, band chunks
     __shared__ __attribute__((aligned(16))) bf16 sK[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sV[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sR[128 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sP[4 * 64 * PT];
+    __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
+    __shared__ __attribute__((aligned(16))) bf16 sP[NW * 64 * PT];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int i0 = qt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
+    const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;           // bytes between consecutive kv rows
@@ -216,14 +226,14 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
     float lpart[4] = {0.f, 0.f, 0.f, 0.f};
 
     int jt_lo, jt_hi;
-    kv_range(a, i0, rst, jt_lo, jt_hi);
+    kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
     bf16* myP = sP + w * 64 * PT;
 
     const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
     const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
     const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
     const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
-    Stager<64, DH> stK, stV, stR;
+    Stager<64, DH, NTHR> stK, stV, stR;
     stK.init(rsb, tid);
     stV.init(rsb, tid);
     stR.init((unsigned)a.ld_rd * 2u, tid);
@@ -235,9 +245,12 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
         stR.load(srdR, (unsigned)dlo * rdb);            // negative dlo wraps: out of range -> zeros
     };
     {   // prologue: high half of the first band, then the first tile
-        const int dhi = i0 + M - jt_lo * 64 - 63 + 64;
-        stR.load(srdR, (unsigned)dhi * rdb);
-        stR.store(sR + 64 * DH);
+#pragma unroll
+        for (int kc = 1; kc < NCH; ++kc) {      // upper chunks of the first band (chunk kc sits in slot kc at t = 0)
+            const int dk = i0 + M - jt_lo * 64 - 63 + 64 * kc;
+            stR.load(srdR, (unsigned)dk * rdb);
+            stR.store(sR + kc * 64 * DH);
+        }
         issue(jt_lo);
         stK.store(sK);
         stV.store(sV);
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int prow = ring_row(16 * w + 16 * blk, t) + r16;
+            const int prow = ring_row<NCH, NCH - 1>(16 * w + 16 * blk, t) + r16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], frag<DH>(sR, prow, 4 * ks + g), qr[blk]);
         }
@@ -268,13 +281,13 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             // named scalars (not an array): `cond ? pm[a] : pm[b]` would be turned into a dynamic index
-            const float p0 = bperm(srcaddr[reg], qr[0][reg]), p1 = bperm(srcaddr[reg], qr[1][reg]),
-                        p2 = bperm(srcaddr[reg], qr[2][reg]), p3 = bperm(srcaddr[reg], qr[3][reg]),
-                        p4 = bperm(srcaddr[reg], qr[4][reg]);
-            s[0][reg] += lower[reg] ? p4 : p3;
-            s[1][reg] += lower[reg] ? p3 : p2;
-            s[2][reg] += lower[reg] ? p2 : p1;
-            s[3][reg] += lower[reg] ? p1 : p0;
+            // select at the SOURCE lane t (dest lane s < row  <=>  t < row), then one permute per output
+            const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
+                        t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
+            s[0][reg] += bperm(srcaddr[reg], t0);
+            s[1][reg] += bperm(srcaddr[reg], t1);
+            s[2][reg] += bperm(srcaddr[reg], t2);
+            s[3][reg] += bperm(srcaddr[reg], t3);
         }
         const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
                                (rst && j0 < M) || (iw_hi >= T);
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
         if (jt < jt_hi) {
             stK.store(sK);
             stV.store(sV);
-            stR.store(sR + (((t + 1) & 1) << 6) * DH);
+            stR.store(sR + ((((NCH - 1) * (t + 1)) % NCH) << 6) * DH);
         }
         __syncthreads();
     }
@@ -358,18 +371,19 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const AttnArgs a) {
 // =============================================================================================
 // backward, q-stationary: dq_AC = dS.K (+ its column sums for d r_w_bias) and dS written by
 // DISTANCE (dSk[i][d = i+M-j]) for the two GEMMs  dq_BD = dSk.Rd  and  dRd = dSk^T.(q+v).
-template <int DH>
-__global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
+    constexpr int QROWS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // query rows per workgroup, band chunks
     __shared__ __attribute__((aligned(16))) bf16 sK[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sV[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sR[128 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sD[4 * 64 * PT];
-    __shared__ float red[4][DH];
+    __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
+    __shared__ __attribute__((aligned(16))) bf16 sD[NW * 64 * PT];
+    __shared__ float red[NW][DH];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int i0 = qt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
+    const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;
@@ -403,14 +417,14 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
     for (int d = 0; d < DB; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int jt_lo, jt_hi;
-    kv_range(a, i0, rst, jt_lo, jt_hi);
+    kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
     bf16* myD = sD + w * 64 * PT;
 
     const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
     const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
     const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
     const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
-    Stager<64, DH> stK, stV, stR;
+    Stager<64, DH, NTHR> stK, stV, stR;
     stK.init(rsb, tid);
     stV.init(rsb, tid);
     stR.init((unsigned)a.ld_rd * 2u, tid);
@@ -422,9 +436,12 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
         stR.load(srdR, (unsigned)dlo * rdb);
     };
     {
-        const int dhi = i0 + M - jt_lo * 64 - 63 + 64;
-        stR.load(srdR, (unsigned)dhi * rdb);
-        stR.store(sR + 64 * DH);
+#pragma unroll
+        for (int kc = 1; kc < NCH; ++kc) {      // upper chunks of the first band (chunk kc sits in slot kc at t = 0)
+            const int dk = i0 + M - jt_lo * 64 - 63 + 64 * kc;
+            stR.load(srdR, (unsigned)dk * rdb);
+            stR.store(sR + kc * 64 * DH);
+        }
         issue(jt_lo);
         stK.store(sK);
         stV.store(sV);
@@ -451,19 +468,19 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int prow = ring_row(16 * w + 16 * blk, t) + r16;
+            const int prow = ring_row<NCH, NCH - 1>(16 * w + 16 * blk, t) + r16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], frag<DH>(sR, prow, 4 * ks + g), qr[blk]);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float p0 = bperm(srcaddr[reg], qr[0][reg]), p1 = bperm(srcaddr[reg], qr[1][reg]),
-                        p2 = bperm(srcaddr[reg], qr[2][reg]), p3 = bperm(srcaddr[reg], qr[3][reg]),
-                        p4 = bperm(srcaddr[reg], qr[4][reg]);
-            s[0][reg] += lower[reg] ? p4 : p3;
-            s[1][reg] += lower[reg] ? p3 : p2;
-            s[2][reg] += lower[reg] ? p2 : p1;
-            s[3][reg] += lower[reg] ? p1 : p0;
+            // select at the SOURCE lane t (dest lane s < row  <=>  t < row), then one permute per output
+            const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
+                        t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
+            s[0][reg] += bperm(srcaddr[reg], t0);
+            s[1][reg] += bperm(srcaddr[reg], t1);
+            s[2][reg] += bperm(srcaddr[reg], t2);
+            s[3][reg] += bperm(srcaddr[reg], t3);
         }
         const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
                                (rst && j0 < M) || (iw_hi >= T);
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
         if (jt < jt_hi) {
             stK.store(sK);
             stV.store(sV);
-            stR.store(sR + (((t + 1) & 1) << 6) * DH);
+            stR.store(sR + ((((NCH - 1) * (t + 1)) % NCH) << 6) * DH);
         }
         __syncthreads();
     }
@@ -558,24 +575,30 @@ __global__ __launch_bounds__(256) void relattn_bwd_q_kernel(const AttnArgs a) {
     }
     __syncthreads();
     if (tid < DH)
-        a.du_part[((size_t)b * gridDim.x + qt) * HD + h * DH + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    {
+        float acc = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) acc += red[ww][tid];
+        a.du_part[((size_t)b * gridDim.x + qt) * HD + h * DH + tid] = acc;
+    }
 }
 
 // =============================================================================================
 // backward, kv-stationary: dk, dv.  Wave w owns kv columns 16w..16w+15 of the tile; S, dP are
 // held as [64 q rows x 16 kv cols] in C layout, which IS the A-operand layout of P^T / dS^T.
-template <int DH>
-__global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
+    constexpr int KCOLS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // key columns per workgroup, band chunks
     __shared__ __attribute__((aligned(16))) bf16 sQu[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sQv[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sdO[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sR[128 * DH];
+    __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
     __shared__ float sLse[64], sDl[64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int jt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int j0 = jt * 64, T = a.T, M = a.M, B = a.B, K = T + M;
+    const int j0 = jt * KCOLS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
     const int HD = a.H * DH;
@@ -605,8 +628,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
     // query tiles that see this kv tile: i >= j - M ; same_length: i < j + sshift
     int it_lo = max(0, j0 - M) >> 6;
     int it_hi = (T - 1) >> 6;
-    if (a.same_length) it_hi = min(it_hi, (j0 + 63 + a.sshift - 1) >> 6);
-    if (rst && j0 + 63 < M) it_hi = -1;          // whole tile is reset memory: no gradient
+    if (a.same_length) it_hi = min(it_hi, (j0 + KCOLS - 1 + a.sshift - 1) >> 6);
+    if (rst && j0 + KCOLS - 1 < M) it_hi = -1;          // whole tile is reset memory: no gradient
     if (it_hi < it_lo) it_hi = it_lo - 1;
 
     const unsigned qsb = (unsigned)B * HD * 2u, osb = (unsigned)B * a.ld_o * 2u, rdb = (unsigned)a.ld_rd * 2u;
@@ -614,14 +637,14 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
     const srd_t srdQv = make_srd(a.qv2 + (size_t)b * HD + h * DH, ((size_t)(T - 1) * B * HD + DH) * 2);
     const srd_t srdO = make_srd(a.dout + (size_t)b * a.ld_o + h * DH, ((size_t)(T - 1) * B * a.ld_o + DH) * 2);
     const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
-    Stager<64, DH> stQu, stQv, stO, stR;
+    Stager<64, DH, NTHR> stQu, stQv, stO, stR;
     stQu.init(qsb, tid);
     stQv.init(qsb, tid);
     stO.init(osb, tid);
     stR.init(rdb, tid);
     float plse = 0.f, pdl = 0.f;
-    auto issue = [&](int it, int half) {          // band half `half` of tile `it`
-        const int i0 = it * 64, dlo = i0 + M - j0 - 63;
+    auto issue = [&](int it, int half) {          // band chunk `half` of tile `it`
+        const int i0 = it * 64, dlo = i0 + M - j0 - (KCOLS - 1);
         stQu.load(srdQu, (unsigned)i0 * qsb);
         stQv.load(srdQv, (unsigned)i0 * qsb);
         stO.load(srdO, (unsigned)i0 * osb);
@@ -640,17 +663,20 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
         if (tid < 64) { sLse[tid] = plse; sDl[tid] = pdl; }
     };
     if (it_lo <= it_hi) {
-        // prologue: low half of the first band (physical half 0), then the tile with its high half
-        const int dlo = it_lo * 64 + M - j0 - 63;
-        stR.load(srdR, (unsigned)dlo * rdb);
-        stR.store(sR);
-        issue(it_lo, 1);
-        commit(sR + 64 * DH);
+        // prologue: lower chunks of the first band (slot k at t = 0), then the tile with its top chunk
+        const int dlo = it_lo * 64 + M - j0 - (KCOLS - 1);
+#pragma unroll
+        for (int kc = 0; kc < NCH - 1; ++kc) {
+            stR.load(srdR, (unsigned)(dlo + 64 * kc) * rdb);
+            stR.store(sR + kc * 64 * DH);
+        }
+        issue(it_lo, NCH - 1);
+        commit(sR + (NCH - 1) * 64 * DH);
     }
     __syncthreads();
     for (int it = it_lo, t = 0; it <= it_hi; ++it, ++t) {
         const int i0 = it * 64;
-        if (it < it_hi) issue(it + 1, 1);
+        if (it < it_hi) issue(it + 1, NCH - 1);
 
         bf16x4 pb[4], dsb[4];     // per row block: P and dS'' for rows 16rb + 4g + reg, col r16
         const int jw_lo = j0 + 16 * w, jw_hi = jw_lo + 15;
@@ -660,8 +686,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
         for (int rb = 0; rb < 4; ++rb) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             f32x4 qr0 = {0.f, 0.f, 0.f, 0.f}, qr1 = {0.f, 0.f, 0.f, 0.f};
-            const int base = 16 * (rb - w) + 48;          // band rows base .. base+31
-            const int pr0 = ring_row(base, t) + r16, pr1 = ring_row(base + 16, t) + r16;
+            const int base = 16 * (rb - w + NW - 1);      // band rows base .. base+31
+            const int pr0 = ring_row<NCH, 1>(base, t) + r16, pr1 = ring_row<NCH, 1>(base + 16, t) + r16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 qvf = frag<DH>(sQv, 16 * rb + r16, 4 * ks + g);
@@ -711,7 +737,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv_kernel(const AttnArgs a) {
             }
         }
         __syncthreads();
-        if (it < it_hi) commit(sR + ((t & 1) << 6) * DH);      // new high half replaces this tile's low half
+        if (it < it_hi) commit(sR + ((t % NCH) << 6) * DH);      // the new top chunk replaces this tile's lowest chunk
         __syncthreads();
     }
 #pragma unroll
@@ -809,10 +835,16 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     AttnArgs a = {};
     fill_common(a, d);
     a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
-    dim3 grid((d->T + 63) / 64, d->H, d->B);
-    if (d->DH == 64) COMMU_LAUNCH(relattn_fwd_kernel<64>, grid, dim3(256), 0, stream, a);
-    else if (d->DH == 32) COMMU_LAUNCH(relattn_fwd_kernel<32>, grid, dim3(256), 0, stream, a);
-    else return -22;
+    const bool wide = d->T >= 128 && getenv("COMMU_ATTN_WIDE");      // 8 waves x 16 query rows per workgroup
+    const int qrows = wide ? 128 : 64;
+    dim3 grid((d->T + qrows - 1) / qrows, d->H, d->B);
+    if (d->DH == 64) {
+        if (wide) COMMU_LAUNCH((relattn_fwd_kernel<64, 8>), grid, dim3(512), 0, stream, a);
+        else COMMU_LAUNCH((relattn_fwd_kernel<64, 4>), grid, dim3(256), 0, stream, a);
+    } else if (d->DH == 32) {
+        if (wide) COMMU_LAUNCH((relattn_fwd_kernel<32, 8>), grid, dim3(512), 0, stream, a);
+        else COMMU_LAUNCH((relattn_fwd_kernel<32, 4>), grid, dim3(256), 0, stream, a);
+    } else return -22;
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -828,14 +860,22 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     a.dq = (bf16*)e->dq_ac; a.dk = (bf16*)e->dk; a.dv = (bf16*)e->dv;
     a.dsk = (bf16*)e->dsk; a.du_part = e->du_part;
     a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk;
-    dim3 gq((d->T + 63) / 64, d->H, d->B), gk((K + 63) / 64, d->H, d->B);
-    if (d->DH == 64) {
-        COMMU_LAUNCH(relattn_bwd_q_kernel<64>, gq, dim3(256), 0, stream, a);
-        COMMU_LAUNCH(relattn_bwd_kv_kernel<64>, gk, dim3(256), 0, stream, a);
-    } else if (d->DH == 32) {
-        COMMU_LAUNCH(relattn_bwd_q_kernel<32>, gq, dim3(256), 0, stream, a);
-        COMMU_LAUNCH(relattn_bwd_kv_kernel<32>, gk, dim3(256), 0, stream, a);
-    } else return -22;
+    const bool narrow = getenv("COMMU_ATTN_WIDE") == nullptr;
+    const bool wq = d->T >= 128 && !narrow, wk = K >= 128 && !narrow;
+    const int qrows = wq ? 128 : 64, kcols = wk ? 128 : 64;
+    if (e->du_rows != (d->T + qrows - 1) / qrows) return -22;
+    dim3 gq((d->T + qrows - 1) / qrows, d->H, d->B), gk((K + kcols - 1) / kcols, d->H, d->B);
+#define ATTN_BWD(DHV)                                                                              \
+    {                                                                                              \
+        if (wq) COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 8>), gq, dim3(512), 0, stream, a);         \
+        else COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4>), gq, dim3(256), 0, stream, a);            \
+        if (wk) COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 8>), gk, dim3(512), 0, stream, a);        \
+        else COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4>), gk, dim3(256), 0, stream, a);           \
+    }
+    if (d->DH == 64) ATTN_BWD(64)
+    else if (d->DH == 32) ATTN_BWD(32)
+    else return -22;
+#undef ATTN_BWD
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -858,3 +898,6 @@ extern "C" int commu_transpose_heads(const void* src, int ld, const float* bias,
     COMMU_LAUNCH_CHECK();
     return 0;
 }
+
+/* query-tile rows the backward kernels use for a given T (du_part has ceil(T / rows) tiles per batch entry) */
+extern "C" int commu_attn_bwd_qrows(int T) { return (T >= 128 && getenv("COMMU_ATTN_WIDE")) ? 128 : 64; }

@@ -154,9 +154,11 @@ typedef struct commu_attn_bwd_desc {
     void* dk;             /* bf16 rows like k with ld_dqkv */
     void* dv;
     void* dsk;            /* bf16 [H][T*B][ld_dsk], ZERO-INITIALISED by the caller */
-    float* du_part;       /* [B*ceil(T/64)][H*DH] column sums of dq_ac per query tile */
+    float* du_part;       /* [B*du_rows][H*DH] column sums of dq_ac per query tile */
     int ld_dqkv, ld_dsk;
+    int du_rows;          /* = ceil(T / commu_attn_bwd_qrows(T)) */
 } commu_attn_bwd_desc;
+int commu_attn_bwd_qrows(int T);
 int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H, int DH,
                      hipStream_t stream);
