@@ -171,6 +171,25 @@ struct Stager {
 template <int NCH, int STEP>
 __device__ __forceinline__ int ring_row(int x, int t) { return ((((x >> 6) + STEP * t) % NCH) << 6) + (x & 63); }
 
+// Workgroups go to the 8 XCDs round-robin by linear id.  Hand every XCD whole (batch, head) pairs: all
+// tiles of a pair share K, V and the band (they hit in that XCD's L2), and the heavy and light tiles of
+// the causal triangle land on the same XCD, so the per-XCD work is balanced.  (A 3-D grid with the tile
+// index fastest puts tile t on XCD t % 8: 2.4x more work on XCD 0 than on XCD 7 at 16 tiles.)
+__device__ __forceinline__ void tile_coords(int ntile, int H, int B, int& tile, int& h, int& b) {
+    const int id = blockIdx.x, NP = H * B;
+    int pair;
+    if ((NP & 7) == 0) {
+        const int slot = id >> 3;
+        pair = (slot / ntile) * 8 + (id & 7);
+        tile = slot % ntile;
+    } else {
+        pair = id / ntile;
+        tile = id % ntile;
+    }
+    b = pair / H;
+    h = pair - b * H;
+}
+
 // =============================================================================================
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) {
@@ -182,7 +201,10 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
     __shared__ __attribute__((aligned(16))) bf16 sP[NW * 64 * PT];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int QT = (a.T + QROWS - 1) / QROWS;
+    int qt, h, b;
+    tile_coords(QT, a.H, a.B, qt, h, b);
+    qt = QT - 1 - qt;                    // heaviest tile of a pair first
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
@@ -382,7 +404,10 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     __shared__ float red[NW][DH];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int QT = (a.T + QROWS - 1) / QROWS;
+    int qt, h, b;
+    tile_coords(QT, a.H, a.B, qt, h, b);
+    qt = QT - 1 - qt;                    // heaviest tile of a pair first
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         float acc = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) acc += red[ww][tid];
-        a.du_part[((size_t)b * gridDim.x + qt) * HD + h * DH + tid] = acc;
+        a.du_part[((size_t)b * QT + qt) * HD + h * DH + tid] = acc;
     }
 }
 
@@ -597,7 +622,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
     __shared__ float sLse[64], sDl[64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    const int jt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int jt, h, b;
+    tile_coords((a.T + a.M + KCOLS - 1) / KCOLS, a.H, a.B, jt, h, b);
     const int j0 = jt * KCOLS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
@@ -837,7 +863,7 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
     const bool wide = d->T >= 128 && getenv("COMMU_ATTN_WIDE");      // 8 waves x 16 query rows per workgroup
     const int qrows = wide ? 128 : 64;
-    dim3 grid((d->T + qrows - 1) / qrows, d->H, d->B);
+    dim3 grid(((d->T + qrows - 1) / qrows) * d->H * d->B);
     if (d->DH == 64) {
         if (wide) COMMU_LAUNCH((relattn_fwd_kernel<64, 8>), grid, dim3(512), 0, stream, a);
         else COMMU_LAUNCH((relattn_fwd_kernel<64, 4>), grid, dim3(256), 0, stream, a);
@@ -864,7 +890,7 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     const bool wq = d->T >= 128 && !narrow, wk = K >= 128 && !narrow;
     const int qrows = wq ? 128 : 64, kcols = wk ? 128 : 64;
     if (e->du_rows != (d->T + qrows - 1) / qrows) return -22;
-    dim3 gq((d->T + qrows - 1) / qrows, d->H, d->B), gk((K + kcols - 1) / kcols, d->H, d->B);
+    dim3 gq(((d->T + qrows - 1) / qrows) * d->H * d->B), gk(((K + kcols - 1) / kcols) * d->H * d->B);
 #define ATTN_BWD(DHV)                                                                              \
     {                                                                                              \
         if (wq) COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 8>), gq, dim3(512), 0, stream, a);         \
