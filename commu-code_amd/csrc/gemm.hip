@@ -31,6 +31,17 @@ struct GemmBatch {          // element strides between consecutive batch entries
 template <int BKT>
 __device__ __forceinline__ int swzk(int row) { return BKT == 64 ? (row & 7) : swz64(row); }
 
+// Which weight row (= output column) sits at LDS row r of the B tile.  Within a wave's 16*NBW columns the
+// MFMA output gives lane (r16, g) the elements (block ni, 4g + reg); staging the columns in this order makes
+// those 4*NBW/... elements 8 CONSECUTIVE output columns per pair of blocks: column = 32*(ni>>1) + 8g + 4*(ni&1)
+// + reg, so the epilogue stores 16 bytes per lane and 64 contiguous bytes per row and instruction.
+template <int NBW>
+__device__ __forceinline__ int colperm(int r) {
+    const int c = r & 15, ni = (r >> 4) & (NBW - 1);
+    if (NBW == 4) return (r & ~63) + 32 * (ni >> 1) + 8 * (c >> 2) + 4 * (ni & 1) + (c & 3);
+    return (r & ~31) + 8 * (c >> 2) + 4 * ni + (c & 3);
+}
+
 // Tile = (16*MBW*WM) x (16*NBW*WN): WM x WN waves, each MBW x NBW MFMA blocks.  Configurations:
 //   <4,4|2,2,2>: 128 x 128|64, 256 threads     <8,4,2,4>: 256 x 256, 512 threads (halves the bytes each
 //   CU loads per flop: the 128x128 tile is bound by the ~15 B/cycle/CU vector-load path, not by MFMA)
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 #pragma unroll
     for (int i = 0; i < NLA; ++i) ap[i] = A + (size_t)min(m0 + lrow + RPP * i, M - 1) * lda + lch * 8;
 #pragma unroll
-    for (int i = 0; i < NLB; ++i) bp[i] = B + (size_t)min(n0 + lrow + RPP * i, N - 1) * ldb + lch * 8;
+    for (int i = 0; i < NLB; ++i) bp[i] = B + (size_t)min(n0 + colperm<NBW>(lrow + RPP * i), N - 1) * ldb + lch * 8;
     bf16x8 ra[NLA], rb[NLB];
     auto gload = [&](int kt) {
 #pragma unroll
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
         const int q = tid + NTHR * i, r = q / CPR, pc = q % CPR;
-        gpb[i] = B + (size_t)min(n0 + r, N - 1) * ldb + ((pc ^ swzk<BKT>(r)) << 3);
+        gpb[i] = B + (size_t)min(n0 + colperm<NBW>(r), N - 1) * ldb + ((pc ^ swzk<BKT>(r)) << 3);
     }
     auto glds = [&](int kt, int buf) {
 #pragma unroll
@@ -132,9 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            if (GLDS) glds(kt + 1, buf ^ 1); else gload(kt + 1);
-        }
+        if (!GLDS && kt + 1 < nk) gload(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             // (all fragment rows are r16 + a multiple of 16, so the swizzle term depends on r16 only)
@@ -144,65 +153,96 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
             for (int i = 0; i < MBW; ++i) af[i] = ld_bf16x8(&sA[buf][(wr * 16 * MBW + 16 * i + r16) * BK + choff]);
 #pragma unroll
             for (int i = 0; i < NBW; ++i) bfr[i] = ld_bf16x8(&sB[buf][(wc * 16 * NBW + 16 * i + r16) * BK + choff]);
+            if (GLDS && ks == BK / 32 - 1) {
+                // the LDS-DMA of the next tile goes out AFTER this tile's last fragment reads: the compiler puts
+                // a vmcnt(0) in front of the first LDS read that follows a DMA, so issuing it earlier would
+                // serialise load -> wait -> MFMA.  Here it flies under the MFMAs below.
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) glds(kt + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int ni = 0; ni < NBW; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MBW; ++mi) acc[ni][mi] = mfma16(bfr[ni], af[mi], acc[ni][mi]);
         }
         if (!GLDS && kt + 1 < nk) lstore(buf ^ 1);
+        if (GLDS) {
+            __builtin_amdgcn_sched_barrier(0);                      // keep the MFMAs above the wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my DMA pieces have landed before the barrier
+        }
         __syncthreads();
     }
 
-    // epilogue: lane holds C[m = .. + r16][n = .. + 4g + reg]
+    // epilogue: lane holds C[m = .. + r16][n = .. + 32*j + 8g + e], e = 4*(ni&1) + reg, ni = 2j + (e>>2)
 #pragma unroll
     for (int mi = 0; mi < MBW; ++mi) {
         const int m = m0 + wr * 16 * MBW + 16 * mi + r16;
         if (m >= M) continue;
 #pragma unroll
-        for (int ni = 0; ni < NBW; ++ni) {
-            const int n = n0 + wc * 16 * NBW + 16 * ni + 4 * g;
+        for (int j = 0; j < NBW / 2; ++j) {
+            const int n = n0 + wc * 16 * NBW + (NBW == 4 ? 32 * j : 0) + 8 * g;
             if (n >= N) continue;
-            f32x4 v = acc[ni][mi];
-            const bool full = (n + 3 < N);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[2 * j + (e >> 2)][mi][e & 3];
+            const bool full = (n + 7 < N);
             if (flags & COMMU_EPI_BIAS) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 8; ++e)
                     if (n + e < N) v[e] += bias[n + e];
             }
             if (flags & COMMU_EPI_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             if (flags & COMMU_EPI_DROPOUT) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 8; ++e)
                     v[e] = drop_keep(drop_seed, (unsigned)m * (unsigned)N + (unsigned)(n + e), drop_thr) ? v[e] * drop_scale : 0.f;
             }
             if (flags & COMMU_EPI_RESID) {
+                const bf16* rp = resid + (size_t)m * ldr + n;
+                if (full && (ldr % 8) == 0) {
+                    const bf16x8 r8 = ld_bf16x8(rp);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < N) v[e] += bf2f(resid[(size_t)m * ldr + n + e]);
+                    for (int e = 0; e < 8; ++e) v[e] += bf2f(r8[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < N) v[e] += bf2f(rp[e]);
+                }
             }
             if (flags & COMMU_EPI_RELUMASK) {
+                const bf16* mp = rmask + (size_t)m * ldm + n;
+                if (full && (ldm % 8) == 0) {
+                    const bf16x8 m8 = ld_bf16x8(mp);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < N) v[e] = (bf2f(rmask[(size_t)m * ldm + n + e]) > 0.f) ? v[e] * mask_scale : 0.f;
+                    for (int e = 0; e < 8; ++e) v[e] = (bf2f(m8[e]) > 0.f) ? v[e] * mask_scale : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < N) v[e] = (bf2f(mp[e]) > 0.f) ? v[e] * mask_scale : 0.f;
+                }
             }
             if (OUT_F32) {
                 float* C = (float*)Cv + coff + (size_t)m * ldc + n;
                 if (full) {
-                    *(f32x4*)C = v;
+                    *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 } else {
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 8; ++e)
                         if (n + e < N) C[e] = v[e];
                 }
             } else {
                 bf16* C = (bf16*)Cv + coff + (size_t)m * ldc + n;
-                if (full) {
-                    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *(bf16x4*)C = o;
+                if (full && (ldc % 8) == 0) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+                    st_bf16x8(C, o);
                 } else {
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 8; ++e)
                         if (n + e < N) C[e] = f2bf(v[e]);
                 }
             }
@@ -406,8 +446,12 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (K <= 0 || (K % 32) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
     const bool narrow = (N <= 64);
-    const bool big = !narrow && M >= 2048 && N >= 256 && (N % 256 == 0 || N >= 1024) && !getenv("COMMU_GEMM_SMALL");
-    const int bn = narrow ? 64 : (big ? 256 : 128), bm = big ? 256 : 128;
+    // large M: 256 x 256 (512 threads) for wide outputs, 256 x 128 (256 threads, two workgroups per CU so one's
+    // epilogue overlaps the other's main loop) otherwise; 128 x 128 for small problems
+    const bool large = !narrow && M >= 2048 && N >= 128 && !getenv("COMMU_GEMM_SMALL");
+    const bool big = large && N >= 1024 && (N % 256 == 0) && !getenv("COMMU_GEMM_TALL");
+    const bool tall = large && !big;
+    const int bn = narrow ? 64 : (tall ? 128 : (big ? 256 : 128)), bm = (big || tall) ? 256 : 128;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     dim3 grid(tiles_m * tiles_n, batch);
     const unsigned drop_thr = (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0);
@@ -417,7 +461,16 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
                  ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags,          \
                  tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs)
     const bool k64 = (K % 64 == 0) && !getenv("COMMU_GEMM_BK32");
-    if (big) {
+    if (tall) {
+        if (flags & COMMU_EPI_OUT_F32)
+            COMMU_LAUNCH((gemm_nt_kernel<true, 4, 32, 8, 2, 2>), grid, dim3(256), 0, stream, (const bf16*)A, lda,
+                         (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask,
+                         ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs);
+        else
+            COMMU_LAUNCH((gemm_nt_kernel<false, 4, 32, 8, 2, 2>), grid, dim3(256), 0, stream, (const bf16*)A, lda,
+                         (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask,
+                         ldm, flags, tiles_n, drop_seed, drop_thr, drop_scale, mask_scale, bs);
+    } else if (big) {
         if (flags & COMMU_EPI_OUT_F32)
             COMMU_LAUNCH((gemm_nt_kernel<true, 4, 32, 8, 2, 4>), grid, dim3(512), 0, stream, (const bf16*)A, lda,
                          (const bf16*)B, ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask,
