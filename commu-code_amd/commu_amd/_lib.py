@@ -28,7 +28,7 @@ class AttnDesc(C.Structure):
 class AttnBwdDesc(C.Structure):
     _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
                 ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
-                ("du_rows", c_i)]
+                ("du_rows", c_i), ("dsk_wedge", c_i)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
@@ -36,9 +36,9 @@ PROTOTYPES = {
     "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, C.c_uint, c_f, c_f, c_p],
     "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_gemm_nt_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_i, c_i,
-                                   c_i, c_p, c_i, C.c_longlong, c_i, c_i, c_p],
+                                   c_i, c_p, c_i, C.c_longlong, c_i, c_i, c_i, c_i, c_p],
     "commu_gemm_tn_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, c_z, c_i, c_i, c_i, c_i,
-                                   c_i, c_p],
+                                   c_i, c_i, c_i, c_p],
     "commu_reduce_slabs2d_f32": [c_p, c_i, C.c_longlong, c_p, c_i, c_i, c_i, c_z, c_i, c_i, c_f, c_p],
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
     "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],

@@ -328,6 +328,9 @@ def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     return out, lse, qs
 
 
+POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prove nothing reads it
+
+
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
                 drd, du, dvb, drop_p=0.0, drop_seed=0):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
@@ -341,7 +344,19 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
     call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
     ld_dsk = round_up(K, 32)
-    dsk = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
+    # dS by distance is lower-triangular (d <= i + M).  Without same_length / reset masks the kernel writes the
+    # triangle plus a wedge of zeros and the two GEMMs below only visit the band: no 1 GB zero-fill per layer,
+    # half the GEMM work.  Wedge >= what a GEMM row tile (128 rows) / output tile (128 columns) can overhang.
+    band = (not same_length) and reset is None
+    if band:
+        wedge = 136 + (128 + B - 1) // B
+        dsk = torch.empty(H, T * B, ld_dsk, device=dev, dtype=BF16)
+        if POISON_SCRATCH:
+            dsk.fill_(float("nan"))
+    else:
+        wedge = 0
+        dsk = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
+    tri_B, tri_M = (B, M) if band else (0, 0)
     dq_ac = torch.empty(T * B, HD, device=dev, dtype=BF16)
     du_part = torch.empty(B * QT, HD, device=dev, dtype=F32)
     d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len, drop_p, drop_seed)
@@ -350,7 +365,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     e.qu2, e.qv2 = qu2.data_ptr(), qv2.data_ptr()
     e.dq_ac, e.dk, e.dv = dq_ac.data_ptr(), dk.data_ptr(), dv.data_ptr()
     e.dsk, e.du_part = dsk.data_ptr(), du_part.data_ptr()
-    e.ld_dqkv, e.ld_dsk, e.du_rows = dk.stride(0), ld_dsk, QT
+    e.ld_dqkv, e.ld_dsk, e.du_rows, e.dsk_wedge = dk.stride(0), ld_dsk, QT, wedge
     assert dv.stride(0) == dk.stride(0)
     call("commu_relattn_bwd", C.byref(d), C.byref(e), _s())
     # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
@@ -358,11 +373,11 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     c2 = d.scale * 1.4426950408889634
     TB = T * B
     call("commu_gemm_nt_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(rdt), ld_dsk, DH * ld_dsk, _p(dq), dq.stride(0),
-         DH, TB, DH, ld_dsk, _p(dq_ac), HD, DH, EPI_RESID, H, _s())
+         DH, TB, DH, ld_dsk, _p(dq_ac), HD, DH, EPI_RESID, H, tri_B, tri_M, _s())
     ns = tn_slices(TB, ld_dsk, DH * H)
     slabs = torch.empty(H * ns * ld_dsk * DH, device=dev, dtype=F32)
     call("commu_gemm_tn_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(qv2), HD, DH, _p(slabs), DH, ld_dsk * DH, TB,
-         ld_dsk, DH, ns, H, _s())
+         ld_dsk, DH, ns, H, tri_B, tri_M, _s())
     call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, ns, ld_dsk * DH, H, 0, 1.0 / c2, _s())
     # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)
     ca = torch.zeros(HD, device=dev, dtype=F32)

@@ -24,6 +24,7 @@ __device__ __forceinline__ int swz64(int row) { return ((row >> 3) & 1) * 3; }
 
 struct GemmBatch {          // element strides between consecutive batch entries (blockIdx.y)
     long long a, b, c, r;
+    int tri_B, tri_M;       // causal band: row m = i*tri_B + b of A is zero beyond column i + tri_M (0: off)
 };
 
 // NBW = 16-column blocks per wave: 4 -> 128-wide tile, 2 -> 64-wide tile (per-head GEMMs, N = d_head)
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 #pragma unroll
         for (int j = 0; j < MBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    int keff = K;
+    if (bs.tri_B > 0) keff = min(K, ((min(m0 + BM, M) - 1) / bs.tri_B + bs.tri_M + 1 + 63) & ~63);
+    const int nk = keff / BK;
     // ---- LDS-DMA staging: chunk q = tid + NTHR*i of a tile lands at LDS byte 16*q; it holds tile row q / CPR,
     // logical chunk (q % CPR) ^ swz(row)
     const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
@@ -265,7 +268,7 @@ template <int NCOLS_B, int MODE>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
     float* __restrict__ C, int ldc, size_t slab_stride, int Mtot, int N, int Kc, int m_per_slice, int nslices,
-    long long strideA, long long strideB) {
+    long long strideA, long long strideB, int tri_B, int tri_M) {
     // image A: [32][128] bf16, image B: [32][NCOLS_B]; double buffered
     __shared__ __attribute__((aligned(16))) bf16 sA[2][TM * 128];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][TM * NCOLS_B];
@@ -280,9 +283,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const int slice = blockIdx.z - batch * nslices;
     A += (long long)batch * strideA;
     B += (long long)batch * strideB;
-    const int mbeg = slice * m_per_slice;
+    int mbeg = slice * m_per_slice;
     const int mend = min(Mtot, mbeg + m_per_slice);
-    const int nsteps = (mend - mbeg + TM - 1) / TM;
+    if (tri_B > 0) mbeg = max(mbeg, (max(n0 - tri_M, 0) * tri_B) & ~(TM - 1));      // rows above the band are zero
+    const int nsteps = max(0, (mend - mbeg + TM - 1) / TM);
 
     const int lrow = tid >> 4, lch = tid & 15;            // 16 rows x 16 chunks(16B) per pass
     constexpr int CHB = NCOLS_B / 8;                      // 16-byte chunks per B row
@@ -496,20 +500,20 @@ extern "C" int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb
                                   const void* relu_mask, int ldm, int flags, unsigned drop_seed, float drop_p,
                                   float mask_scale, hipStream_t stream) {
     return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, resid, ldr, relu_mask, ldm, flags, drop_seed, drop_p,
-                          mask_scale, 1, GemmBatch{0, 0, 0, 0}, stream);
+                          mask_scale, 1, GemmBatch{0, 0, 0, 0, 0, 0}, stream);
 }
 
 extern "C" int commu_gemm_nt_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
                                           long long strideB, void* C, int ldc, long long strideC, int M, int N,
                                           int K, const void* resid, int ldr, long long strideR, int flags,
-                                          int batch, hipStream_t stream) {
+                                          int batch, int tri_B, int tri_M, hipStream_t stream) {
     return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, nullptr, resid, ldr, nullptr, 0, flags, 0u, 0.f, 1.f, batch,
-                          GemmBatch{strideA, strideB, strideC, strideR}, stream);
+                          GemmBatch{strideA, strideB, strideC, strideR, tri_B, tri_M}, stream);
 }
 
 static int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc, size_t slab_stride,
                           int M, int N, int K, int nslices, int mode, int batch, long long strideA, long long strideB,
-                          hipStream_t stream) {
+                          int tri_B, int tri_M, hipStream_t stream) {
     if (N <= 0 || K <= 0 || nslices <= 0 || batch <= 0) return 0;
     if ((lda % 8) || (ldb % 8) || (ldc % 4) || (N % 8) || (K % 8)) return -22;
     int mps = (M + nslices - 1) / nslices;
@@ -518,7 +522,7 @@ static int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float*
     dim3 grid((N + 127) / 128, narrow ? (K + 63) / 64 : (K + 127) / 128, nslices * batch);
 #define TN_LAUNCH(NC, MD)                                                                          \
     COMMU_LAUNCH((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,        \
-                 (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps, nslices, strideA, strideB)
+                 (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps, nslices, strideA, strideB, tri_B, tri_M)
     if (narrow) {
         if (mode) TN_LAUNCH(64, 1); else TN_LAUNCH(64, 0);
     } else {
@@ -532,14 +536,16 @@ static int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float*
 extern "C" int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs,
                                   int ldc, size_t slab_stride, int M, int N, int K, int nslices,
                                   int mode, hipStream_t stream) {
-    return launch_gemm_tn(A, lda, B, ldb, slabs, ldc, slab_stride, M, N, K, nslices, mode, 1, 0, 0, stream);
+    return launch_gemm_tn(A, lda, B, ldb, slabs, ldc, slab_stride, M, N, K, nslices, mode, 1, 0, 0, 0, 0, stream);
 }
 
 /* batch entry z: slabs[(z*nslices + s)][n,k] */
 extern "C" int commu_gemm_tn_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
                                           long long strideB, float* slabs, int ldc, size_t slab_stride, int M,
-                                          int N, int K, int nslices, int batch, hipStream_t stream) {
-    return launch_gemm_tn(A, lda, B, ldb, slabs, ldc, slab_stride, M, N, K, nslices, 1, batch, strideA, strideB, stream);
+                                          int N, int K, int nslices, int batch, int tri_B, int tri_M,
+                                          hipStream_t stream) {
+    return launch_gemm_tn(A, lda, B, ldb, slabs, ldc, slab_stride, M, N, K, nslices, 1, batch, strideA, strideB, tri_B,
+                          tri_M, stream);
 }
 
 extern "C" int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs,

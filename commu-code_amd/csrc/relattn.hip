@@ -49,6 +49,7 @@ struct AttnArgs {
     bf16* dsk;          // [H][T*B][ld_dsk]  dS indexed by distance d (zero-initialised by the caller)
     float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
+    int dsk_wedge;      // > 0: dsk is uninitialised; zero columns i+M+1 .. i+M+dsk_wedge of every row (band GEMM contract)
     int T, M, B, H;
     int same_length, sshift;
     float scale;
@@ -583,6 +584,15 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         }
         __syncthreads();
     }
+    if (a.dsk_wedge > 0) {          // zeros right of the causal edge, as far as the band GEMMs read
+        for (int r = 0; r < 16; ++r) {
+            const int i = iw_lo + r;
+            if (i >= T) break;
+            bf16* drow = a.dsk + ((size_t)h * mrow0 + (size_t)i * B + b) * a.ld_dsk;
+            const int dbeg = i + M + 1, dend = min(a.ld_dsk, dbeg + a.dsk_wedge);
+            for (int d = dbeg + lane; d < dend; d += 64) drow[d] = f2bf(0.f);
+        }
+    }
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
         float ca = 0.f;
@@ -886,6 +896,8 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     a.dq = (bf16*)e->dq_ac; a.dk = (bf16*)e->dk; a.dv = (bf16*)e->dv;
     a.dsk = (bf16*)e->dsk; a.du_part = e->du_part;
     a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk;
+    a.dsk_wedge = e->dsk_wedge;
+    if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
     const bool narrow = getenv("COMMU_ATTN_WIDE") == nullptr;
     const bool wq = d->T >= 128 && !narrow, wk = K >= 128 && !narrow;
     const int qrows = wq ? 128 : 64, kcols = wk ? 128 : 64;

@@ -42,19 +42,23 @@ int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, 
                        int ldm, int flags, unsigned drop_seed, float drop_p, float mask_scale,
                        hipStream_t stream);
 /* batched form: entry z uses A + z*strideA, B + z*strideB, C + z*strideC, resid + z*strideR (element
- * strides); a 64-wide tile is used when N <= 64 (per-head GEMMs).  Epilogue flags: RESID, OUT_F32. */
+ * strides); a 64-wide tile is used when N <= 64 (per-head GEMMs).  Epilogue flags: RESID, OUT_F32.
+ * Causal band (tri_B > 0): A is dS by distance, row m = i*tri_B + b is zero (or unwritten) beyond column
+ * i + tri_M, so a row tile only contracts columns < i_max + tri_M + 1 (rounded up to 64): the caller
+ * guarantees ZEROS in each row from column i + tri_M + 1 up to that limit (commu_attn_bwd_desc.dsk_wedge). */
 int commu_gemm_nt_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
                                long long strideB, void* C, int ldc, long long strideC, int M, int N, int K,
                                const void* resid, int ldr, long long strideR, int flags, int batch,
-                               hipStream_t stream);
+                               int tri_B, int tri_M, hipStream_t stream);
 /* slabs[s][n,k] = sum_{m in slice s} A[m,n] * B[m,k]  (weight gradients dW = dY^T X).
  * mode 1: LDS transpose reads (ds_read_b64_tr_b16); mode 0: 16-bit gathers. */
 int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc,
                        size_t slab_stride, int M, int N, int K, int nslices, int mode, hipStream_t stream);
-/* batched form: slabs[(z*nslices + s)][n,k] for batch entry z */
+/* batched form: slabs[(z*nslices + s)][n,k] for batch entry z.  Causal band (tri_B > 0): column n of A is
+ * zero (or unwritten) in rows m < (n - tri_M) * tri_B, so an output tile starting at n0 skips those rows. */
 int commu_gemm_tn_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
                                long long strideB, float* slabs, int ldc, size_t slab_stride, int M, int N, int K,
-                               int nslices, int batch, hipStream_t stream);
+                               int nslices, int batch, int tri_B, int tri_M, hipStream_t stream);
 /* dst[z][r*ldd + c] = (accumulate ? dst : 0) + alpha * sum_s src[(z*nslabs + s)*stride + r*cols + c] */
 int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, const float* src, int rows, int cols,
                              int nslabs, size_t stride, int batch, int accumulate, float alpha, hipStream_t stream);
@@ -153,10 +157,14 @@ typedef struct commu_attn_bwd_desc {
     void* dq_ac;          /* bf16 [T*B][H*DH] */
     void* dk;             /* bf16 rows like k with ld_dqkv */
     void* dv;
-    void* dsk;            /* bf16 [H][T*B][ld_dsk], ZERO-INITIALISED by the caller */
+    void* dsk;            /* bf16 [H][T*B][ld_dsk]: dS by distance d = i + M - j.  dsk_wedge == 0: ZERO-INITIALISED by
+                             the caller; dsk_wedge > 0: uninitialised -- the kernel writes columns 0..i+M of row
+                             (i, b) and zeros columns i+M+1 .. i+M+dsk_wedge; the rest is never read by the band
+                             GEMMs (only valid without same_length / reset masks) */
     float* du_part;       /* [B*du_rows][H*DH] column sums of dq_ac per query tile */
     int ld_dqkv, ld_dsk;
     int du_rows;          /* = ceil(T / commu_attn_bwd_qrows(T)) */
+    int dsk_wedge;
 } commu_attn_bwd_desc;
 int commu_attn_bwd_qrows(int T);
 int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);

@@ -262,6 +262,11 @@ ATTN_CASES = [
     (70, 130, 2, 1, 64, True, 150, 1),
     (1, 77, 2, 2, 32, True, 4146, None),
     (200, 0, 1, 1, 64, False, 0, None),
+    # causal-band mode of the backward (no same_length / reset): several GEMM row tiles, memory, B = 1 wedge
+    (100, 60, 2, 2, 64, False, 64, None),
+    (300, 40, 3, 1, 64, False, 40, None),
+    (520, 0, 1, 2, 32, False, 0, None),
+    (257, 31, 5, 1, 64, False, 31, None),
 ]
 
 
@@ -320,8 +325,12 @@ def test_relattn_bwd(case):
     dqkv = torch.zeros_like(g)
     drd = torch.zeros(K, HD, device=DEV)
     du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
-    o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
-                  dout.to(DEV), lse, qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+    o.POISON_SCRATCH = True           # NaN in every scratch element the kernels are not supposed to read
+    try:
+        o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
+                      dout.to(DEV), lse, qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+    finally:
+        o.POISON_SCRATCH = False
     gref = leaf.grad
     tol = 2.5e-2          # bf16 P/dS operands + bf16 outputs
     assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol, "dq"
