@@ -37,6 +37,7 @@ PROTOTYPES = {
     "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_gemm_nt_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_i, c_i,
                                    c_i, c_p, c_i, C.c_longlong, c_i, c_i, c_i, c_i, c_p],
+    "commu_gemm_tn_slices": [c_i, c_i, c_i],
     "commu_gemm_tn_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, c_z, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_i, c_p],
     "commu_reduce_slabs2d_f32": [c_p, c_i, C.c_longlong, c_p, c_i, c_i, c_i, c_z, c_i, c_i, c_f, c_p],

@@ -121,10 +121,8 @@ def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None
 
 
 def tn_slices(M: int, N: int, K: int) -> int:
-    """Number of m-slices so that the grid has >= ~512 workgroups."""
-    tiles = ((N + 127) // 128) * ((K + 63) // 64 if K <= 64 else (K + 127) // 128)
-    s = max(1, min(64, (512 + tiles - 1) // tiles))
-    return max(1, min(s, (M + 255) // 256))
+    """Number of m-slices the TN kernel wants at this shape (enough workgroups to fill the GPU)."""
+    return _lib.load().commu_gemm_tn_slices(int(M), int(N), int(K))
 
 
 def gemm_tn(A, B, out, *, accumulate=False, slabs=None, mode=None):

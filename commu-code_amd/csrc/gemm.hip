@@ -259,74 +259,82 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 // consecutive m per lane) are columns of the staged [32 m][128] LDS images.
 //   mode 1: ds_read_b64_tr_b16 transpose reads (2 per fragment)
 //   mode 0: ds_read_u16 gathers (8 per fragment) -- slow, correct by construction.
-constexpr int TM = 32;
+constexpr int TM = 64;      // contraction rows per pipeline step (two MFMA k-steps)
 
 // swizzle of the 32-byte unit index (8 units per 256-byte row... 128 cols) used by the TN images
 __device__ __forceinline__ int swz_tn(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <int NCOLS_B, int MODE>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(
+typedef __amdgpu_buffer_rsrc_t tn_srd_t;
+
+// Tile BNA (n) x BNB (k), WR x WC waves; TMS contraction rows per pipeline step.  Configurations:
+//   <128,128,2,2,64>, <128,64,2,2,64> (per-head outputs, K <= 64): 256 threads
+//   <256,256,2,4,32>: 512 threads, wave tile 128 x 64 -- halves the bytes each CU pulls through its vector-load
+//   path per flop (the 128 x 128 tile runs at ~13 B/cycle/CU of L2->LDS traffic, its limit)
+template <int BNA, int BNB, int WR, int WC, int TMS, int MODE>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_tn_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb,
     float* __restrict__ C, int ldc, size_t slab_stride, int Mtot, int N, int Kc, int m_per_slice, int nslices,
     long long strideA, long long strideB, int tri_B, int tri_M) {
-    // image A: [32][128] bf16, image B: [32][NCOLS_B]; double buffered
-    __shared__ __attribute__((aligned(16))) bf16 sA[2][TM * 128];
-    __shared__ __attribute__((aligned(16))) bf16 sB[2][TM * NCOLS_B];
-    constexpr int WN = 64;                 // wave tile: 64 (n) x NCOLS_B/2 (k)
-    constexpr int WK = NCOLS_B / 2;
-    constexpr int KB = WK / 16;            // k blocks per wave (4 or 2)
+    constexpr int NTHR = 64 * WR * WC;
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][TMS * BNA];      // [m][n] images, double buffered
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][TMS * BNB];
+    constexpr int WN = BNA / WR, WK = BNB / WC;      // wave tile
+    constexpr int NB = WN / 16, KB = WK / 16;        // MFMA blocks per wave
+    constexpr int SWA = (BNA / 16 - 1) & 7, SWB = (BNB / 16 - 1) & 7;      // swizzle masks (32-byte units per row - 1, <= 7)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wr = w >> 1, wc = w & 1, r16 = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * NCOLS_B;
+    const int wr = w / WC, wc = w % WC, r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * BNA, k0 = blockIdx.y * BNB;
     const int batch = blockIdx.z / nslices;
     const int slice = blockIdx.z - batch * nslices;
     A += (long long)batch * strideA;
     B += (long long)batch * strideB;
     int mbeg = slice * m_per_slice;
     const int mend = min(Mtot, mbeg + m_per_slice);
-    if (tri_B > 0) mbeg = max(mbeg, (max(n0 - tri_M, 0) * tri_B) & ~(TM - 1));      // rows above the band are zero
-    const int nsteps = max(0, (mend - mbeg + TM - 1) / TM);
+    if (tri_B > 0) mbeg = max(mbeg, (max(n0 - tri_M, 0) * tri_B) & ~(TMS - 1));      // rows above the band are zero
+    const int nsteps = max(0, (mend - mbeg + TMS - 1) / TMS);
 
-    const int lrow = tid >> 4, lch = tid & 15;            // 16 rows x 16 chunks(16B) per pass
-    constexpr int CHB = NCOLS_B / 8;                      // 16-byte chunks per B row
-    const int browB = tid / CHB, bchB = tid % CHB;
-    constexpr int ROWS_PER_PASS_B = 256 / CHB;            // 16 (128 cols) or 32 (64 cols)
-    bf16x8 ra[2], rb[2];
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // staging with buffer loads: rows >= mend (and the bytes past column N / Kc of the last row) lie outside the
+    // SRD's range and read as zero -- no predicates.  Tile columns >= N (or Kc) are forced out of range.
+    const tn_srd_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0,
+        mend > 0 ? (int)(unsigned)((((size_t)(mend - 1)) * lda + N) * 2) : 0, 0x00020000);
+    const tn_srd_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0,
+        mend > 0 ? (int)(unsigned)((((size_t)(mend - 1)) * ldb + Kc) * 2) : 0, 0x00020000);
+    constexpr int CHA = BNA / 8, CHB = BNB / 8;              // 16-byte chunks per image row
+    constexpr int RPA = NTHR / CHA, RPB = NTHR / CHB;        // rows per pass of all threads
+    constexpr int NLA = TMS / RPA, NLB = TMS / RPB;
+    static_assert(NLA >= 1 && NLB >= 1 && TMS % RPA == 0 && TMS % RPB == 0, "staging shape");
+    const int arow = tid / CHA, ach = tid % CHA, brow = tid / CHB, bch = tid % CHB;
+    bf16x8 ra[NLA], rb[NLB];
+    const unsigned aoff = ((unsigned)arow * lda + n0 + ach * 8) * 2u, boff = ((unsigned)brow * ldb + k0 + bch * 8) * 2u;
+    const bool acol = n0 + ach * 8 < N, bcol = k0 + bch * 8 < Kc;      // (whole 16-byte chunks: N, Kc % 8 == 0)
     auto gload = [&](int st) {
-        const int mb = mbeg + st * TM;
+        const unsigned mb = (unsigned)(mbeg + st * TMS);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = mb + lrow + 16 * i;
-            const int n = n0 + lch * 8;
-            ra[i] = (m < mend && n < N) ? ld_bf16x8(A + (size_t)m * lda + n) : zero8;
-        }
+        for (int i = 0; i < NLA; ++i)
+            ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                srdA, acol ? (int)(aoff + (mb + RPA * i) * (unsigned)lda * 2u) : -16, 0, 0));
 #pragma unroll
-        for (int i = 0; i < TM / ROWS_PER_PASS_B; ++i) {
-            const int m = mb + browB + ROWS_PER_PASS_B * i;
-            const int k = k0 + bchB * 8;
-            rb[i] = (m < mend && k < Kc) ? ld_bf16x8(B + (size_t)m * ldb + k) : zero8;
-        }
+        for (int i = 0; i < NLB; ++i)
+            rb[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                srdB, bcol ? (int)(boff + (mb + RPB * i) * (unsigned)ldb * 2u) : -16, 0, 0));
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = lrow + 16 * i;
-            const int ch = (((lch >> 1) ^ swz_tn(r)) << 1) | (lch & 1);
-            st_bf16x8(&sA[buf][r * 128 + ch * 8], ra[i]);
+        for (int i = 0; i < NLA; ++i) {
+            const int r = arow + RPA * i;
+            const int ch = (((ach >> 1) ^ (swz_tn(r) & SWA)) << 1) | (ach & 1);
+            st_bf16x8(&sA[buf][r * BNA + ch * 8], ra[i]);
         }
 #pragma unroll
-        for (int i = 0; i < TM / ROWS_PER_PASS_B; ++i) {
-            const int r = browB + ROWS_PER_PASS_B * i;
-            int ch;
-            if (NCOLS_B == 128) ch = (((bchB >> 1) ^ swz_tn(r)) << 1) | (bchB & 1);
-            else ch = (((bchB >> 1) ^ (swz_tn(r) & 3)) << 1) | (bchB & 1);
-            st_bf16x8(&sB[buf][r * NCOLS_B + ch * 8], rb[i]);
+        for (int i = 0; i < NLB; ++i) {
+            const int r = brow + RPB * i;
+            const int ch = (((bch >> 1) ^ (swz_tn(r) & SWB)) << 1) | (bch & 1);
+            st_bf16x8(&sB[buf][r * BNB + ch * 8], rb[i]);
         }
     };
-    // fragment = 8 consecutive m (8g .. 8g+7) of column `col` of an image with `ncols` columns
-    auto frag = [&](const bf16* img, int ncols, int colbase) -> bf16x8 {
+    // fragment = 8 consecutive m (8g .. 8g+7) of column `col` of a 32-row image with `ncols` columns
+    auto frag = [&](const bf16* img, int ncols, int swm, int colbase) -> bf16x8 {
         bf16x8 f;
         if (MODE == 1) {
             // lane i of a 16-lane group supplies &img[8g + (i>>2) (+4)][colbase + 4*(i&3)]
@@ -335,8 +343,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int r = 8 * g + (i >> 2) + 4 * h;
-                const int sw = (ncols == 128) ? swz_tn(r) : (swz_tn(r) & 3);
-                const int unit = (c >> 4) ^ sw;
+                const int unit = (c >> 4) ^ (swz_tn(r) & swm);
                 const bf16* p = img + r * ncols + unit * 16 + (c & 15);
                 typedef __attribute__((ext_vector_type(4))) short s16x4;
                 s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(p));
@@ -348,19 +355,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 8 * g + e;
-                const int sw = (ncols == 128) ? swz_tn(r) : (swz_tn(r) & 3);
-                const int unit = (c >> 4) ^ sw;
+                const int unit = (c >> 4) ^ (swz_tn(r) & swm);
                 f[e] = img[r * ncols + unit * 16 + (c & 15)];
             }
         }
         return f;
     };
 
-    f32x4 acc[KB][4];
+    f32x4 acc[KB][NB];
 #pragma unroll
     for (int i = 0; i < KB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (nsteps > 0) {
         gload(0);
@@ -370,22 +376,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
         if (st + 1 < nsteps) gload(st + 1);
-        bf16x8 af[4], bfr[KB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag(sA[buf], 128, wr * WN + 16 * i);
+        for (int ks = 0; ks < TMS / 32; ++ks) {
+            bf16x8 af[NB], bfr[KB];
 #pragma unroll
-        for (int i = 0; i < KB; ++i) bfr[i] = frag(sB[buf], NCOLS_B, wc * WK + 16 * i);
-        // swapped issue: D[k][n] -> lane holds out[n = .. + r16][k = .. + 4g + reg]
+            for (int i = 0; i < NB; ++i) af[i] = frag(sA[buf] + 32 * ks * BNA, BNA, SWA, wr * WN + 16 * i);
 #pragma unroll
-        for (int ki = 0; ki < KB; ++ki)
+            for (int i = 0; i < KB; ++i) bfr[i] = frag(sB[buf] + 32 * ks * BNB, BNB, SWB, wc * WK + 16 * i);
+            // swapped issue: D[k][n] -> lane holds out[n = .. + r16][k = .. + 4g + reg]
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[ki][ni] = mfma16(bfr[ki], af[ni], acc[ki][ni]);
+            for (int ki = 0; ki < KB; ++ki)
+#pragma unroll
+                for (int ni = 0; ni < NB; ++ni) acc[ki][ni] = mfma16(bfr[ki], af[ni], acc[ki][ni]);
+        }
         if (st + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
     float* Cs = C + (size_t)blockIdx.z * slab_stride;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NB; ++ni) {
         const int n = n0 + wr * WN + 16 * ni + r16;
         if (n >= N) continue;
 #pragma unroll
@@ -511,22 +520,48 @@ extern "C" int commu_gemm_nt_bf16_batched(const void* A, int lda, long long stri
                           GemmBatch{strideA, strideB, strideC, strideR, tri_B, tri_M}, stream);
 }
 
+// tile choice of the TN GEMM (shared by the launcher and commu_gemm_tn_slices)
+static int tn_tile(int M, int N, int K) {          // 0: 128x64, 1: 128x128, 2: 256x256
+    if (K <= 64) return 0;
+    if (N >= 256 && K >= 256 && M >= 8192 && !getenv("COMMU_TN_SMALL")) return 2;
+    return 1;
+}
+
+extern "C" int commu_gemm_tn_slices(int M, int N, int K) {
+    const int t = tn_tile(M, N, K);
+    int s;
+    if (t == 2) {          // one 512-thread workgroup per CU: fill the 256 CUs once, never 1.03 times
+        const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+        s = 256 / tiles;
+    } else {
+        const int tiles = ((N + 127) / 128) * (t == 0 ? (K + 63) / 64 : (K + 127) / 128);
+        s = (512 + tiles - 1) / tiles;
+    }
+    s = s < 64 ? s : 64;
+    const int cap = (M + 255) / 256;
+    s = s < cap ? s : cap;
+    return s > 1 ? s : 1;
+}
+
 static int launch_gemm_tn(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc, size_t slab_stride,
                           int M, int N, int K, int nslices, int mode, int batch, long long strideA, long long strideB,
                           int tri_B, int tri_M, hipStream_t stream) {
     if (N <= 0 || K <= 0 || nslices <= 0 || batch <= 0) return 0;
     if ((lda % 8) || (ldb % 8) || (ldc % 4) || (N % 8) || (K % 8)) return -22;
+    if ((size_t)M * lda * 2 >= 0xFFFFFFF0ull || (size_t)M * ldb * 2 >= 0xFFFFFFF0ull) return -22;      // 32-bit buffer offsets
+    const int t = tn_tile(M, N, K);
     int mps = (M + nslices - 1) / nslices;
-    mps = ((mps + TM - 1) / TM) * TM;
-    const bool narrow = (K <= 64);
-    dim3 grid((N + 127) / 128, narrow ? (K + 63) / 64 : (K + 127) / 128, nslices * batch);
-#define TN_LAUNCH(NC, MD)                                                                          \
-    COMMU_LAUNCH((gemm_tn_kernel<NC, MD>), grid, dim3(256), 0, stream, (const bf16*)A, lda,        \
-                 (const bf16*)B, ldb, slabs, ldc, slab_stride, M, N, K, mps, nslices, strideA, strideB, tri_B, tri_M)
-    if (narrow) {
-        if (mode) TN_LAUNCH(64, 1); else TN_LAUNCH(64, 0);
+    mps = ((mps + 63) / 64) * 64;
+#define TN_LAUNCH(BNA, BNB, WR, WC, TMS, MD)                                                                   \
+    COMMU_LAUNCH((gemm_tn_kernel<BNA, BNB, WR, WC, TMS, MD>), dim3((N + BNA - 1) / BNA, (K + BNB - 1) / BNB,   \
+                 nslices * batch), dim3(64 * WR * WC), 0, stream, (const bf16*)A, lda, (const bf16*)B, ldb,    \
+                 slabs, ldc, slab_stride, M, N, K, mps, nslices, strideA, strideB, tri_B, tri_M)
+    if (t == 0) {
+        if (mode) TN_LAUNCH(128, 64, 2, 2, 32, 1); else TN_LAUNCH(128, 64, 2, 2, 32, 0);
+    } else if (t == 2 && mode) {
+        TN_LAUNCH(256, 256, 2, 4, 32, 1);
     } else {
-        if (mode) TN_LAUNCH(128, 1); else TN_LAUNCH(128, 0);
+        if (mode) TN_LAUNCH(128, 128, 2, 2, 32, 1); else TN_LAUNCH(128, 128, 2, 2, 32, 0);
     }
 #undef TN_LAUNCH
     COMMU_LAUNCH_CHECK();

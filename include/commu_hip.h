@@ -54,6 +54,8 @@ int commu_gemm_nt_bf16_batched(const void* A, int lda, long long strideA, const 
  * mode 1: LDS transpose reads (ds_read_b64_tr_b16); mode 0: 16-bit gathers. */
 int commu_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* slabs, int ldc,
                        size_t slab_stride, int M, int N, int K, int nslices, int mode, hipStream_t stream);
+/* recommended number of m-slices for the tile the TN kernel picks at this shape (fills the 256 CUs) */
+int commu_gemm_tn_slices(int M, int N, int K);
 /* batched form: slabs[(z*nslices + s)][n,k] for batch entry z.  Causal band (tri_B > 0): column n of A is
  * zero (or unwritten) in rows m < (n - tri_M) * tri_B, so an output tile starting at n0 skips those rows. */
 int commu_gemm_tn_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
