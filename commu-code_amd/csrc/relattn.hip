@@ -60,7 +60,7 @@ struct AttnArgs {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr int PT = 20;      // pitch (elements) of a per-wave transposed tile [64 kv][16 rows]
+constexpr int PT = 16;      // pitch (elements) of a per-wave transposed tile [64 kv][16 rows]: 4 rows = 128 contiguous bytes per tr-read group
 
 template <int COLS>
 __device__ __forceinline__ int swz(int row) {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void tile_coords(int ntile, int H, int B, int& tile, 
 }
 
 // =============================================================================================
-template <int DH, int NW>
+template <int DH, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     constexpr int QROWS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // query rows per workgroup, band chunks
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
         for (int c = 0; c < 4; ++c) {
             bf16x4 pb;
             unsigned hw[2] = {0u, 0u};
-            if (a.drop_thr) {          // one hash word per (row pair, column): 16 bits per element
+            if (DROP) {          // one hash word per (row pair, column): 16 bits per element
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp)
                     hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
             for (int reg = 0; reg < 4; ++reg) {
                 float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
                 lpart[reg] += p;                               // the normaliser is the un-dropped sum
-                if (a.drop_thr) p = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? p * a.drop_scale : 0.f;
+                if (DROP) p = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? p * a.drop_scale : 0.f;
                 pb[reg] = f2bf(p);
             }
             *(bf16x4*)(myP + (16 * c + r16) * PT + 4 * g) = pb;       // P^T[kv][row]: rows 4g..4g+3
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
 // =============================================================================================
 // backward, q-stationary: dq_AC = dS.K (+ its column sums for d r_w_bias) and dS written by
 // DISTANCE (dSk[i][d = i+M-j]) for the two GEMMs  dq_BD = dSk.Rd  and  dRd = dSk^T.(q+v).
-template <int DH, int NW>
+template <int DH, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     constexpr int QROWS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // query rows per workgroup, band chunks
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         for (int c = 0; c < 4; ++c) {
             bf16x4 db;
             unsigned hw[2] = {0u, 0u};
-            if (a.drop_thr) {
+            if (DROP) {
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp)
                     hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             for (int reg = 0; reg < 4; ++reg) {
                 const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);
                 float dpe = dp[c][reg];
-                if (a.drop_thr) dpe = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? dpe * a.drop_scale : 0.f;
+                if (DROP) dpe = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? dpe * a.drop_scale : 0.f;
                 const float ds = p * (dpe - dl[reg]) * a.scale;
                 s[c][reg] = ds;
                 db[reg] = f2bf(ds);
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
 // =============================================================================================
 // backward, kv-stationary: dk, dv.  Wave w owns kv columns 16w..16w+15 of the tile; S, dP are
 // held as [64 q rows x 16 kv cols] in C layout, which IS the A-operand layout of P^T / dS^T.
-template <int DH, int NW>
+template <int DH, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     constexpr int KCOLS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // key columns per workgroup, band chunks
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                 qr1 = mfma16(qvf, frag<DH>(sR, pr1, 4 * ks + g), qr1);
             }
             unsigned hw[2] = {0u, 0u};
-            if (a.drop_thr) {
+            if (DROP) {
 #pragma unroll
                 for (int rp = 0; rp < 2; ++rp)
                     hw[rp] = mix32(seed_bh + (unsigned)((i0 + 16 * rb + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(jw_lo + r16));
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                     sc = -INFINITY;
                 const float p = __builtin_amdgcn_exp2f(sc - sLse[ii]);
                 float pd = p, dpe = dp[reg];
-                if (a.drop_thr) {
+                if (DROP) {
                     const bool keep = ((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr;
                     pd = keep ? p * a.drop_scale : 0.f;
                     dpe = keep ? dpe * a.drop_scale : 0.f;
@@ -871,16 +871,19 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     AttnArgs a = {};
     fill_common(a, d);
     a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
-    const bool wide = d->T >= 128 && getenv("COMMU_ATTN_WIDE");      // 8 waves x 16 query rows per workgroup
-    const int qrows = wide ? 128 : 64;
-    dim3 grid(((d->T + qrows - 1) / qrows) * d->H * d->B);
-    if (d->DH == 64) {
-        if (wide) COMMU_LAUNCH((relattn_fwd_kernel<64, 8>), grid, dim3(512), 0, stream, a);
-        else COMMU_LAUNCH((relattn_fwd_kernel<64, 4>), grid, dim3(256), 0, stream, a);
-    } else if (d->DH == 32) {
-        if (wide) COMMU_LAUNCH((relattn_fwd_kernel<32, 8>), grid, dim3(512), 0, stream, a);
-        else COMMU_LAUNCH((relattn_fwd_kernel<32, 4>), grid, dim3(256), 0, stream, a);
-    } else return -22;
+    // (the kernels are parametrised by waves per workgroup; 8-wave / 128-row tiles measured slower than 4-wave
+    // tiles at every shape of this model, so only NW = 4 is instantiated)
+    dim3 grid(((d->T + 63) / 64) * d->H * d->B);
+    const bool drop = a.drop_thr != 0u;
+#define ATTN_FWD(DHV)                                                                              \
+    {                                                                                              \
+        if (drop) COMMU_LAUNCH((relattn_fwd_kernel<DHV, 4, true>), grid, dim3(256), 0, stream, a); \
+        else COMMU_LAUNCH((relattn_fwd_kernel<DHV, 4, false>), grid, dim3(256), 0, stream, a);     \
+    }
+    if (d->DH == 64) ATTN_FWD(64)
+    else if (d->DH == 32) ATTN_FWD(32)
+    else return -22;
+#undef ATTN_FWD
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -898,17 +901,18 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk;
     a.dsk_wedge = e->dsk_wedge;
     if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
-    const bool narrow = getenv("COMMU_ATTN_WIDE") == nullptr;
-    const bool wq = d->T >= 128 && !narrow, wk = K >= 128 && !narrow;
-    const int qrows = wq ? 128 : 64, kcols = wk ? 128 : 64;
-    if (e->du_rows != (d->T + qrows - 1) / qrows) return -22;
-    dim3 gq(((d->T + qrows - 1) / qrows) * d->H * d->B), gk(((K + kcols - 1) / kcols) * d->H * d->B);
-#define ATTN_BWD(DHV)                                                                              \
-    {                                                                                              \
-        if (wq) COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 8>), gq, dim3(512), 0, stream, a);         \
-        else COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4>), gq, dim3(256), 0, stream, a);            \
-        if (wk) COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 8>), gk, dim3(512), 0, stream, a);        \
-        else COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4>), gk, dim3(256), 0, stream, a);           \
+    if (e->du_rows != (d->T + 63) / 64) return -22;
+    dim3 gq(((d->T + 63) / 64) * d->H * d->B), gk(((K + 63) / 64) * d->H * d->B);
+    const bool drop = a.drop_thr != 0u;
+#define ATTN_BWD(DHV)                                                                                  \
+    {                                                                                                  \
+        if (drop) {                                                                                    \
+            COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4, true>), gq, dim3(256), 0, stream, a);           \
+            COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4, true>), gk, dim3(256), 0, stream, a);          \
+        } else {                                                                                       \
+            COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4, false>), gq, dim3(256), 0, stream, a);          \
+            COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4, false>), gk, dim3(256), 0, stream, a);         \
+        }                                                                                              \
     }
     if (d->DH == 64) ATTN_BWD(64)
     else if (d->DH == 32) ATTN_BWD(32)
@@ -938,4 +942,4 @@ extern "C" int commu_transpose_heads(const void* src, int ld, const float* bias,
 }
 
 /* query-tile rows the backward kernels use for a given T (du_part has ceil(T / rows) tiles per batch entry) */
-extern "C" int commu_attn_bwd_qrows(int T) { return (T >= 128 && getenv("COMMU_ATTN_WIDE")) ? 128 : 64; }
+extern "C" int commu_attn_bwd_qrows(int T) { (void)T; return 64; }
