@@ -112,6 +112,23 @@ def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
             "klen_start": klen0, "steps": steps, "hipgraph": bool(graph)}
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json,
+    produced by tests/probes/pmc_traffic.sh at the DEFAULT bench shape: FETCH_SIZE x 2 (gfx950 correction of
+    MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both in KiB -> bytes).  None when the shape differs from
+    the profiled one or the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // args.batch_chunk]
+    if rec.get("shape") != shape:
+        return None
+    return rec.get("bytes_per_launch", {}).get(kernel)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,7 +186,8 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    prof_names = ["commu_relattn_bwd", "commu_relattn_fwd", "commu_gemm_nt_bf16", "commu_gemm_tn_bf16"]
+    prof_names = ["commu_relattn_bwd_kv", "commu_relattn_bwd_q", "commu_relattn_fwd", "commu_gemm_nt_bf16",
+                  "commu_gemm_tn_bf16"]
     # (4 event pairs per entry-point call: ~1 us each on the host, < 2% of a step)
     _lib.profile_start(prof_names)
     torch.cuda.synchronize()
@@ -194,22 +212,21 @@ def main():
     L, D, DI, T, M, H = args.layers, args.d_model, args.d_inner, args.tgt_len, args.mem_len, args.heads
     f_fwd = fwd_flops_per_token(L, D, DI, T, M)
     step_flops = 3.0 * f_fwd * tokens_per_step
-    # dominant kernel: rel-pos attention backward (dq + dk/dv kernels), algorithmic flops per launch =
-    # 2x the forward attention flops: tokens * 6*Kbar*D * 2   
+    # Roofline of the dominant SINGLE kernel: the three attention entry points launch exactly one kernel at one
+    # shape (the GEMM entry points are a mix of shapes and tile variants; their share is in time_share).
+    # Algorithmic flops per launch = tokens * products * 2*Kbar*D  (Kbar = M + (T+1)/2):
+    #   forward 3 products (QK^T, QR^T, PV); query-stationary backward 4 (QK^T, QR^T, dP, dQ);
+    #   key-stationary backward 5 (QK^T, QR^T, dP, dV, dK).
     mb_tokens = tokens_per_step // args.batch_chunk
     kbar = M + (T + 1) / 2.0
-    attn_fwd_flops = mb_tokens * 6.0 * kbar * D
+    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 5.0}
     tot = {k: sum(v) for k, v in prof.items()}
     cnt = {k: max(1, len(v)) for k, v in prof.items()}
-    dom = max(tot, key=tot.get)
-    flops_per_launch = {"commu_relattn_bwd": 2.0 * attn_fwd_flops, "commu_relattn_fwd": attn_fwd_flops}
-    if dom in flops_per_launch:
-        fl_launch = flops_per_launch[dom]
-    else:   # GEMMs: 2*(8D^2 + 4*D*DI)*L + 2*D*V per token fwd; fwd NT + dX NT launches, dW TN launches
-        gemm_fwd = mb_tokens * (L * (8 * D * D + 4 * D * DI) + 2 * D * 729)
-        fl_launch = (2.0 if dom == "commu_gemm_nt_bf16" else 1.0) * gemm_fwd * args.batch_chunk * args.steps / cnt[dom]
+    dom = max(products, key=lambda k: tot.get(k, 0.0))
+    fl_launch = mb_tokens * products[dom] * 2.0 * kbar * D
     avg_ms = tot[dom] / cnt[dom]
     achieved = fl_launch / (avg_ms * 1e-3) / 1e12
+    traffic = pmc_traffic(dom, args)
     out = {
         "metric": "training tokens/sec at d_model=512 tgt_len=1024",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,7 +239,8 @@ def main():
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
         "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "flops_per_launch": fl_launch,
                      "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
                      "time_share": {k: round(tot[k] / (1e3 * elapsed), 4) for k in tot}},
     }

@@ -365,7 +365,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     e.dsk, e.du_part = dsk.data_ptr(), du_part.data_ptr()
     e.ld_dqkv, e.ld_dsk, e.du_rows, e.dsk_wedge = dk.stride(0), ld_dsk, QT, wedge
     assert dv.stride(0) == dk.stride(0)
-    call("commu_relattn_bwd", C.byref(d), C.byref(e), _s())
+    call("commu_relattn_bwd_q", C.byref(d), C.byref(e), _s())
+    call("commu_relattn_bwd_kv", C.byref(d), C.byref(e), _s())
     # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
     rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
     c2 = d.scale * 1.4426950408889634

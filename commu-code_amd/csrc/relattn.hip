@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
     __shared__ __attribute__((aligned(16))) bf16 sQv[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sdO[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
-    __shared__ float sLse[64], sDl[64];
+    __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     int jt, h, b;
@@ -738,6 +738,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                 for (int rp = 0; rp < 2; ++rp)
                     hw[rp] = mix32(seed_bh + (unsigned)((i0 + 16 * rb + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(jw_lo + r16));
             }
+            const f32x4 lse4 = *(const f32x4*)&sLse[16 * rb + 4 * g], dl4 = *(const f32x4*)&sDl[16 * rb + 4 * g];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const float p0 = bperm(srcaddr[reg], qr0[reg]);
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                 float sc = s[reg] + (lower[reg] ? p1 : p0);
                 if (need_mask && (is_masked(i0 + ii, jw_lo + r16, M, a.same_length, a.sshift, rst) || i0 + ii >= T))
                     sc = -INFINITY;
-                const float p = __builtin_amdgcn_exp2f(sc - sLse[ii]);
+                const float p = __builtin_amdgcn_exp2f(sc - lse4[reg]);
                 float pd = p, dpe = dp[reg];
                 if (DROP) {
                     const bool keep = ((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr;
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                     dpe = keep ? dpe * a.drop_scale : 0.f;
                 }
                 pb[rb][reg] = f2bf(pd);
-                dsb[rb][reg] = f2bf(p * (dpe - sDl[ii]) * LN2);           // (q+u) is pre-scaled: scale/c2 = ln2
+                dsb[rb][reg] = f2bf(p * (dpe - dl4[reg]) * LN2);           // (q+u) is pre-scaled: scale/c2 = ln2
             }
         }
         // dv += P^T dO ; dk += dS''^T qu2: k-slots e<4 -> ii = 32pp+4g+e, e>=4 -> ii = 32pp+16+4g+e-4
@@ -888,7 +889,8 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     return 0;
 }
 
-extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream) {
+// which: 1 = query-stationary kernel (dq_ac, dsk, du_part), 2 = key-stationary kernel (dk, dv), 3 = both
+static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, int which, hipStream_t stream) {
     if (d->T <= 0 || d->B <= 0) return 0;
     const int K = d->T + d->M;
     if ((d->ld_qkv % 8) || (d->ld_rd % 8) || (e->ld_dqkv % 8) || !fits_srd(d) || e->ld_dsk < K) return -22;
@@ -904,15 +906,15 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
     if (e->du_rows != (d->T + 63) / 64) return -22;
     dim3 gq(((d->T + 63) / 64) * d->H * d->B), gk(((K + 63) / 64) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
-#define ATTN_BWD(DHV)                                                                                  \
-    {                                                                                                  \
-        if (drop) {                                                                                    \
-            COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4, true>), gq, dim3(256), 0, stream, a);           \
-            COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4, true>), gk, dim3(256), 0, stream, a);          \
-        } else {                                                                                       \
-            COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4, false>), gq, dim3(256), 0, stream, a);          \
-            COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4, false>), gk, dim3(256), 0, stream, a);         \
-        }                                                                                              \
+#define ATTN_BWD(DHV)                                                                                                  \
+    {                                                                                                                  \
+        if (drop) {                                                                                                    \
+            if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4, true>), gq, dim3(256), 0, stream, a);            \
+            if (which & 2) COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4, true>), gk, dim3(256), 0, stream, a);           \
+        } else {                                                                                                       \
+            if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<DHV, 4, false>), gq, dim3(256), 0, stream, a);           \
+            if (which & 2) COMMU_LAUNCH((relattn_bwd_kv_kernel<DHV, 4, false>), gk, dim3(256), 0, stream, a);          \
+        }                                                                                                              \
     }
     if (d->DH == 64) ATTN_BWD(64)
     else if (d->DH == 32) ATTN_BWD(32)
@@ -920,6 +922,16 @@ extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_
 #undef ATTN_BWD
     COMMU_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream) {
+    return launch_relattn_bwd(d, e, 3, stream);
+}
+extern "C" int commu_relattn_bwd_q(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream) {
+    return launch_relattn_bwd(d, e, 1, stream);
+}
+extern "C" int commu_relattn_bwd_kv(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream) {
+    return launch_relattn_bwd(d, e, 2, stream);
 }
 
 extern "C" int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H,

@@ -170,6 +170,10 @@ typedef struct commu_attn_bwd_desc {
 } commu_attn_bwd_desc;
 int commu_attn_bwd_qrows(int T);
 int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
+/* the two kernels of commu_relattn_bwd on their own: query-stationary (dq_ac, dsk, du_part) and key-stationary
+ * (dk, dv); same descriptors */
+int commu_relattn_bwd_q(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
+int commu_relattn_bwd_kv(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H, int DH,
                      hipStream_t stream);
 /* dst[((b*H+h)*DH+f)*W + off + j] = src[(j*B+b)*ld + h*DH + f] (+ bias[h*DH+f]); zero elsewhere */
