@@ -163,52 +163,65 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 // dy*xhat (dgamma), dy (dbeta) and dz (bias grad of the Linear feeding the LN) per block.
 constexpr int LNB_ROWS = 64;   // rows per block (16 per wave)
 
+template <int NC>          // NC 8-element chunks per lane: D <= 512 * NC
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ z, int ldz,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     bf16* __restrict__ dz, int lddz, float* __restrict__ part, int rows, int D, bf16* __restrict__ dzm,
     int lddzm, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
-    __shared__ float red[4][3][1024];
+    __shared__ float red[4][3][512 * NC];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float ag[LN_MAXC][8], ab[LN_MAXC][8], az[LN_MAXC][8], gm[LN_MAXC][8];
+    float ag[NC][8], ab[NC][8], az[NC][8], gm[NC][8];
+    bool act[NC];
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c)
+    for (int c = 0; c < NC; ++c) {
+        act[c] = lane * 8 + 512 * c < D;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             ag[c][e] = ab[c][e] = az[c][e] = 0.f;
             const int col = lane * 8 + 512 * c + e;
             gm[c][e] = (col < D) ? gamma[col] : 0.f;
         }
+    }
     const int r0 = blockIdx.x * LNB_ROWS + w * 16;
-    for (int rr = 0; rr < 16; ++rr) {
+    const int nr = min(16, rows - r0);
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 vz[NC], vd[NC], nz[NC], nd[NC];
+    auto fetch = [&](int row, bf16x8* pz, bf16x8* pd) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = lane * 8 + 512 * c;
+            pz[c] = act[c] ? ld_bf16x8(z + (size_t)row * ldz + col) : zero8;
+            pd[c] = act[c] ? ld_bf16x8(dy + (size_t)row * lddy + col) : zero8;
+        }
+    };
+    if (nr > 0) fetch(r0, nz, nd);
+    for (int rr = 0; rr < nr; ++rr) {
         const int row = r0 + rr;
-        if (row >= rows) break;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { vz[c] = nz[c]; vd[c] = nd[c]; }
+        if (rr + 1 < nr) fetch(row + 1, nz, nd);          // next row's loads fly under this row's reductions
         const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAXC][8], gy[LN_MAXC][8];
+        float xh[NC][8], gy[NC][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
-            const int col = lane * 8 + 512 * c;
-            if (col < D) {
-                bf16x8 vz = ld_bf16x8(z + (size_t)row * ldz + col);
-                bf16x8 vd = ld_bf16x8(dy + (size_t)row * lddy + col);
+        for (int c = 0; c < NC; ++c) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float d = bf2f(vd[e]);
-                    xh[c][e] = (bf2f(vz[e]) - mu) * rs;
-                    gy[c][e] = d * gm[c][e];
-                    s1 += gy[c][e];
-                    s2 += gy[c][e] * xh[c][e];
-                    ag[c][e] += d * xh[c][e];
-                    ab[c][e] += d;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float d = bf2f(vd[c][e]);
+                xh[c][e] = act[c] ? (bf2f(vz[c][e]) - mu) * rs : 0.f;
+                gy[c][e] = d * gm[c][e];
+                s1 += gy[c][e];
+                s2 += gy[c][e] * xh[c][e];
+                ag[c][e] += d * xh[c][e];
+                ab[c][e] += d;
             }
         }
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int col = lane * 8 + 512 * c;
-            if (col < D) {
+            if (act[c]) {
                 bf16x8 o, om;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         }
     }
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int col = lane * 8 + 512 * c + e;
@@ -269,6 +282,41 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
     if (c < cols) {
         const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         atomicAdd(out + c, s);
+    }
+}
+
+// bf16 fast path: 16-byte loads (8 columns per lane, 512 per workgroup), 4 rows in flight per wave
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16* __restrict__ X, int ldx, int rows, int cols,
+                                                            float* __restrict__ out, int rows_per_block) {
+    __shared__ float red[4][512];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    const int rbeg = blockIdx.y * rows_per_block;
+    const int rend = min(rows, rbeg + rows_per_block);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {          // (cols % 8 == 0: whole chunks)
+        int r = rbeg + w;
+        for (; r + 12 < rend; r += 16) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld_bf16x8(X + (size_t)(r + 4 * u) * ldx + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += bf2f(v[u][e]);
+        }
+        for (; r < rend; r += 4) {
+            const bf16x8 v = ld_bf16x8(X + (size_t)r * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += bf2f(v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = a[e];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 512; t += 256) {
+        const int c = blockIdx.x * 512 + t;
+        if (c < cols) atomicAdd(out + c, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
     }
 }
 
@@ -506,16 +554,30 @@ extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int 
                                    unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (rows <= 0) return 0;
     if (D > 1024 || (D % 8)) return -22;
-    COMMU_LAUNCH(layernorm_bwd_kernel, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
-                       (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz,
-                       part, rows, D, (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p),
-                       1.f / (1.f - drop_p));
+    if (D <= 512)
+        COMMU_LAUNCH(layernorm_bwd_kernel<1>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
+                     (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,
+                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+    else
+        COMMU_LAUNCH(layernorm_bwd_kernel<2>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
+                     (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,
+                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream) {
     if (rows <= 0 || cols <= 0) return 0;
+    if ((cols % 8) == 0 && (ldx % 8) == 0) {
+        const int nx = (cols + 511) / 512;
+        int ny = (rows + 63) / 64;
+        const int cap = (512 + nx - 1) / nx;           // ~512 workgroups: enough loads in flight, few same-address atomics
+        if (ny > cap) ny = cap;
+        const int rpb = (rows + ny - 1) / ny;
+        COMMU_LAUNCH(colsum_bf16x8_kernel, dim3(nx, ny), dim3(256), 0, stream, (const bf16*)X, ldx, rows, cols, out, rpb);
+        COMMU_LAUNCH_CHECK();
+        return 0;
+    }
     int ny = (rows + 255) / 256;
     if (ny > 256) ny = 256;
     const int rpb = (rows + ny - 1) / ny;

@@ -28,3 +28,7 @@ Wo = torch.randn(512, 512, device="cuda").bfloat16()
 us = t(lambda: ops.gemm_nt(A, Wo, out=out2)); print("gemm o_net        %.1f us  %.0f TF" % (us, 2*65536*512*512/us/1e6))
 g32 = torch.zeros(1536, 512, device="cuda")
 us = t(lambda: ops.gemm_tn(out, A, g32)); print("gemm_tn dWqkv     %.1f us  %.0f TF" % (us, 2*65536*512*1536/us/1e6))
+X5 = torch.randn(65536, 512, device="cuda").bfloat16(); X10 = torch.randn(65536, 1024, device="cuda").bfloat16()
+o5 = torch.zeros(512, device="cuda"); o10 = torch.zeros(1024, device="cuda")
+print("colsum 512        %.1f us" % t(lambda: ops.colsum(X5, o5)))
+print("colsum 1024       %.1f us" % t(lambda: ops.colsum(X10, o10)))
