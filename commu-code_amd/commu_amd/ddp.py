@@ -2,9 +2,12 @@
 train.py:467-473 and the scalar all-reduces of :172-174,209-210).
 
 One process per GPU; the gradients live in ONE flat fp32 buffer, so the exchange is a handful of
-large all-reduces over RCCL/xGMI (`backend="nccl"` is RCCL on ROCm) issued once per optimiser
-step, bucket by bucket in the order the backward pass finishes them, on a side stream.  The
-same code runs on CPU tensors with the `gloo` backend (tests).
+large all-reduces over RCCL/xGMI (`backend="nccl"` is RCCL on ROCm), once per optimiser step.
+OVERLAP: the backward schedule finishes the layers top-down and reports each layer's slice of the
+flat buffer through `model.grad_ready_hook`; slices are merged into buckets and every full bucket
+is all-reduced asynchronously right away (RCCL's stream orders itself after the kernels enqueued
+so far and runs beside the rest of the backward pass); `finish` exchanges what is left (embedding,
+shared biases, a partial bucket) and waits.  The same code runs on CPU tensors with `gloo` (tests).
 """
 from __future__ import annotations
 
@@ -49,6 +52,47 @@ class GradReducer:
             h.wait()
         if not avg:
             flat_g.mul_(1.0 / self.world)
+
+    # ---- overlapped exchange (one optimiser step): begin -> range_ready* -> finish
+    def begin(self):
+        self._handles, self._fired, self._pending = [], [], None
+
+    def _fire(self, flat_g, a, b):
+        avg = flat_g.is_cuda
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+        self._fired.append((a, b))
+
+    def range_ready(self, flat_g, lo, hi):
+        """model.grad_ready_hook: flat_g[lo:hi] is final.  Ranges arrive top layer first (descending)."""
+        if self.world == 1:
+            return
+        if self._pending is not None and self._pending[0] == hi:
+            self._pending = (lo, self._pending[1])
+        else:
+            if self._pending is not None:
+                self._fire(flat_g, *self._pending)
+            self._pending = (lo, hi)
+        if self._pending[1] - self._pending[0] >= self.bucket_elems:
+            self._fire(flat_g, *self._pending)
+            self._pending = None
+
+    def finish(self, flat_g):
+        if self.world == 1:
+            return
+        if self._pending is not None:
+            self._fire(flat_g, *self._pending)
+            self._pending = None
+        pos = 0
+        for a, b in sorted(self._fired) + [(flat_g.numel(), flat_g.numel())]:      # the uncovered rest
+            if a > pos:
+                self._fire(flat_g, pos, a)
+            pos = max(pos, b)
+        for h in self._handles:
+            h.wait()
+        if not flat_g.is_cuda:
+            flat_g.mul_(1.0 / self.world)
+        self._handles = []
 
     def allreduce_mean(self, model):
         fl = model._ensure_flat()

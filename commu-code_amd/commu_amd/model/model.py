@@ -488,6 +488,12 @@ class MemTransformerLM(nn.Module):
             if M > 0:
                 self._tn_acc(dqkv[:M * B, HD:], sv.cat[i], gW[HD:])
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
+            hook = getattr(self, "grad_ready_hook", None)
+            if hook is not None and direct:
+                # every gradient of layer i is final (and enqueued): its slice of the flat buffer may be exchanged
+                lo = gname[pre + "dec_attn.qkv_net.weight"]
+                hi = gname[f"layers.{i + 1}.dec_attn.qkv_net.weight"] if i + 1 < L else gname["crit.out_layers.0.bias"]
+                hook(G, lo, hi)
         ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0))
         if direct:
             return tuple(None for _ in params)

@@ -86,14 +86,26 @@ class Trainer:
         target_chunks = torch.chunk(target, chunk, 1)
         reset_chunks = torch.chunk(reset_mems, chunk, 0)
         total = None
+        overlap = self.reducer is not None and getattr(model, "grad_mode", "") == "direct"
         for i in range(chunk):
             d, t, r = data_chunks[i].contiguous(), target_chunks[i].contiguous(), reset_chunks[i].contiguous()
             loss, self.mems[i] = model(d, t, r, self.mems[i])
             loss = masked_mean(loss, t, self.pad_id, 1.0 / chunk)
-            loss.backward()
+            if overlap and i == chunk - 1:
+                # gradients are complete once the LAST micro-batch's backward has passed a layer: exchange that
+                # layer's slice while the layers below are still being differentiated
+                self.reducer.begin()
+                model.grad_ready_hook = self.reducer.range_ready
+            try:
+                loss.backward()
+            finally:
+                model.grad_ready_hook = None
             total = loss.detach() if total is None else total + loss.detach()
         if self.reducer is not None:
-            self.reducer.allreduce_mean(model)
+            if overlap:
+                self.reducer.finish(model._ensure_flat()["g"])
+            else:
+                self.reducer.allreduce_mean(model)
         grad_norm = clip_grad_norm_(model, cfg.TRAIN.clip, self.optimizer)
         self.optimizer.step()
         self.optimizer.zero_grad()

@@ -50,6 +50,21 @@ def _worker(rank, world, port, q):
         ok = ok and bool((m.fl["p"] == 0).all()) and m.refreshed == 1
         red.allreduce_mean(m)
         ok = ok and torch.allclose(m.fl["g"], torch.full((1000,), (1 + world) / 2.0))
+        # overlapped protocol: layer slices arrive top-down while "backward" is still running; head and tail
+        # (shared biases + embedding, output bias) are only covered by finish()
+        n2 = 50_000
+        g2 = torch.arange(n2, dtype=torch.float32) * (rank + 1)
+        red2 = GradReducer(bucket_mb=0.05)          # 13107 elements per bucket
+        red2.begin()
+        for lo, hi in [(40_000, 49_000), (31_000, 40_000), (22_000, 31_000), (13_000, 22_000), (4_000, 13_000)]:
+            red2.range_ready(g2, lo, hi)
+        fired_early = list(red2._fired)
+        red2.finish(g2)
+        expect2 = torch.arange(n2, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        ok = ok and torch.allclose(g2, expect2, rtol=1e-6)
+        ok = ok and fired_early == [(31_000, 49_000), (13_000, 31_000)]      # two merged buckets before finish
+        cover = sorted(red2._fired)
+        ok = ok and cover[0][0] == 0 and cover[-1][1] == n2 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -194,3 +194,31 @@ def test_state_dict_roundtrip_and_no_cpu_path(golden_dir):
     cpu_model = type(model)(model.cfg, [0] * 729)
     with pytest.raises(CommuHipError):
         cpu_model(torch.zeros(4, 2, dtype=torch.long), torch.zeros(4, 2, dtype=torch.long), None, None)
+
+
+def test_grad_ready_hook_reports_layer_slices_top_down(golden_dir):
+    """The overlapped gradient exchange (commu_amd/ddp.py) relies on this contract: after layer i's backward
+    has been enqueued, flat_g[lo:hi] covers exactly the parameters of layer i, and layers come top-down."""
+    z = load(golden_dir, "g1_train_nomem.npz")
+    model, cfg = build_from_fixture(z)
+    model.eval()
+    data, target = torch.from_numpy(z["data0"]).to(DEV), torch.from_numpy(z["target0"]).to(DEV)
+    seen = []
+    model.grad_ready_hook = lambda G, lo, hi: seen.append((G.data_ptr(), lo, hi))
+    loss, _ = model(data, target, torch.zeros(data.shape[1], dtype=torch.bool, device=DEV), None)
+    loss[target != 0].float().mean().backward()
+    model.grad_ready_hook = None
+    fl = model._ensure_flat()
+    L = model.n_layer
+    assert len(seen) == L and all(ptr == fl["g"].data_ptr() for ptr, _, _ in seen)
+    offs = {n: o for (n, _), o in zip(model.named_parameters(), fl["offs"])}
+    for k, (_, lo, hi) in enumerate(seen):
+        i = L - 1 - k
+        names = [n for n in offs if n.startswith(f"layers.{i}.")]
+        assert lo == min(offs[n] for n in names)
+        assert hi >= max(offs[n] + dict(model.named_parameters())[n].numel() for n in names)
+        nxt = [o for n, o in offs.items() if o >= hi]
+        assert not nxt or min(nxt) == hi                     # ends exactly where the next parameter starts
+        for n in names:                                      # and the slice aliases the parameters' .grad
+            p = dict(model.named_parameters())[n]
+            assert p.grad.data_ptr() == fl["g"].data_ptr() + 4 * offs[n]
