@@ -74,3 +74,54 @@ class FusedAdam(torch.optim.Optimizer):
                       beta1=grp["betas"][0], beta2=grp["betas"][1], eps=grp["eps"])
         self.model._refresh_shadows(cast=False)
         fl["version"] = sum(p._version for p in fl["params"])
+
+    # ---- checkpointing in torch.optim.Adam's own layout (train.py:39-41 saves optimizer.state_dict()): state is
+    # indexed by parameter position, which is model.parameters() order here as in the reference
+    def state_dict(self):
+        fl = self.model._ensure_flat()
+        grp = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        for k, v in (("amsgrad", False), ("maximize", False), ("foreach", None), ("capturable", False),
+                     ("differentiable", False), ("fused", None)):
+            grp.setdefault(k, v)
+        grp["params"] = list(range(len(fl["params"])))
+        state = {}
+        if fl["m"] is not None:
+            for idx, (p, off) in enumerate(zip(fl["params"], fl["offs"])):
+                n = p.numel()
+                state[idx] = {"step": torch.tensor(float(self.step_count)),
+                              "exp_avg": fl["m"][off:off + n].view(p.shape).detach().cpu().clone(),
+                              "exp_avg_sq": fl["v"][off:off + n].view(p.shape).detach().cpu().clone()}
+        return {"state": state, "param_groups": [grp]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        fl = self.model._ensure_flat()
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(fl["params"]):
+            raise CommuHipError("optimizer state does not match this model (one group, %d parameters expected)"
+                                % len(fl["params"]))
+        for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+            if k in groups[0]:
+                self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        if float(self.param_groups[0].get("weight_decay", 0.0)) != 0.0:
+            raise CommuHipError("weight_decay != 0 is not supported")
+        state = sd.get("state", {})
+        if not state:
+            fl["m"], fl["v"], self.step_count = None, None, 0
+            return
+        fl["m"] = torch.zeros_like(fl["p"])
+        fl["v"] = torch.zeros_like(fl["p"])
+        steps = set()
+        for idx, (p, off) in enumerate(zip(fl["params"], fl["offs"])):
+            st = state.get(idx, state.get(str(idx)))
+            if st is None:
+                raise CommuHipError(f"optimizer state misses parameter {idx}")
+            n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise CommuHipError(f"optimizer state of parameter {idx} has shape {tuple(st['exp_avg'].shape)}")
+            fl["m"][off:off + n].copy_(st["exp_avg"].reshape(-1).to(fl["m"].device, torch.float32))
+            fl["v"][off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(fl["v"].device, torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) != 1:
+            raise CommuHipError("per-parameter step counts differ: not an Adam state this kernel can resume")
+        self.step_count = steps.pop()

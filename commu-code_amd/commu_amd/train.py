@@ -138,7 +138,21 @@ class Trainer:
 
 
 def save_checkpoint(path, model, optimizer, vocab, train_step, best_val_loss, scheduler):
-    """train.py:29-54: same dictionary layout (model = unwrapped state_dict, amp = None)."""
+    """train.py:29-54: same dictionary layout (model = unwrapped state_dict, optimizer in torch.optim.Adam's
+    layout, amp = None) -- loadable by the reference and vice versa."""
     torch.save({"model": {k: v.detach().float().cpu() for k, v in model.state_dict().items()},
-                "optimizer": None, "train_step": train_step, "scheduler": scheduler.state_dict(),
+                "optimizer": optimizer.state_dict() if optimizer is not None else None,
+                "train_step": train_step, "scheduler": scheduler.state_dict(),
                 "best_val_loss": best_val_loss, "vocab": vocab, "amp": None}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None):
+    """Resume from a checkpoint written by save_checkpoint or by the reference (train.py:493-495 reads
+    checkpoint["model"]).  Returns (train_step, best_val_loss)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["model"])
+    if optimizer is not None and ck.get("optimizer") is not None:
+        optimizer.load_state_dict(ck["optimizer"])
+    if scheduler is not None and ck.get("scheduler") is not None:
+        scheduler.load_state_dict(ck["scheduler"])
+    return ck.get("train_step", 0), ck.get("best_val_loss")

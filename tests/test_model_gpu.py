@@ -222,3 +222,51 @@ def test_grad_ready_hook_reports_layer_slices_top_down(golden_dir):
         for n in names:                                      # and the slice aliases the parameters' .grad
             p = dict(model.named_parameters())[n]
             assert p.grad.data_ptr() == fl["g"].data_ptr() + 4 * offs[n]
+
+
+def test_checkpoint_roundtrip_resumes_identically(tmp_path):
+    """save_checkpoint / load_checkpoint (train.py:29-54 layout): model + Adam moments + step + LR schedule.
+    A resumed trainer must produce the same parameters as the one that never stopped, and the optimizer state
+    must be loadable by torch.optim.Adam (what the reference would do with it)."""
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import Trainer, build_model, load_checkpoint, save_checkpoint
+    cfg = get_cfg(num_layers=2, num_heads=2, units=64, inner_size=128, tgt_length=32, mem_length=32,
+                  batch_size=4, batch_chunk=1, dropout=0.0, attention_dropout=0.0)
+    dev = torch.device(DEV)
+    batches = [synthetic_batch(32, 4, dev, seed=50 + i) for i in range(5)]
+
+    def run(tr, lo, hi):
+        for i in range(lo, hi):
+            tr.step(*batches[i])
+
+    a = Trainer(build_model(cfg, BaseVocab(), dev, seed=1), cfg)
+    run(a, 0, 3)
+    path = str(tmp_path / "checkpoint_last.pt")
+    save_checkpoint(path, a.model, a.optimizer, BaseVocab(), a.train_step, 1.25, a.scheduler)
+    run(a, 3, 5)
+
+    b = Trainer(build_model(cfg, BaseVocab(), dev, seed=99), cfg)          # different init: must be overwritten
+    step, best = load_checkpoint(path, b.model, b.optimizer, b.scheduler)
+    assert step == 3 and best == 1.25 and b.optimizer.step_count == 3
+    b.train_step = step
+    b.mems = [None]
+    a2 = Trainer(build_model(cfg, BaseVocab(), dev, seed=1), cfg)          # reference run without XL memory carry-over
+    run(a2, 0, 3)
+    a2.mems = [None]
+    run(a2, 3, 5)
+    run(b, 3, 5)
+    for (n, p), (_, q) in zip(a2.model.named_parameters(), b.model.named_parameters()):
+        # (bias gradients are reduced with float atomics: allow last-bit differences)
+        assert torch.allclose(p, q, rtol=0, atol=1e-5), n
+
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    ref_params = [torch.nn.Parameter(v.clone()) for k, v in ck["model"].items()
+                  if k in dict(a.model.named_parameters())]
+    order = [n for n, _ in a.model.named_parameters()]
+    ref_params = [torch.nn.Parameter(ck["model"][n].clone()) for n in order]
+    adam = torch.optim.Adam(ref_params, lr=0.004)
+    adam.load_state_dict(ck["optimizer"])
+    st = adam.state[ref_params[3]]
+    assert float(st["step"]) == 3.0 and st["exp_avg"].shape == ref_params[3].shape
+    assert float(st["exp_avg_sq"].abs().sum()) > 0
