@@ -41,12 +41,14 @@ class DecodeState:
         fl = model._ensure_flat()
         dev = fl["dev"]
         self.model, self.B, self.Lmax = model, B, Lmax
-        L, HD, D = model.n_layer, model.n_head * model.d_head, model.d_model
-        H, DH = model.n_head, model.d_head
+        # kernel-side dimensions (zero-padded when the model's are not multiples of 64 / 32, see model.py)
+        L, D = model.n_layer, model._Dp
+        H, DH = model.n_head, model._DHp
+        HD = H * DH
         self.kc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)      # head-major: contiguous per (b, h)
         self.vc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)
         self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
-        pd = ops.posemb(model.pos_emb.inv_freq, Lmax, D)
+        pd = ops.posemb(model.pos_emb.inv_freq, Lmax, model.d_model, ld=D)
         self.rd = [ops.gemm_nt(pd, model._weights(i)["r"]) for i in range(L)]
         self.logits = torch.zeros(B, 768, device=dev, dtype=F32)
         self.qkv = torch.zeros(B, 3 * HD, device=dev, dtype=BF16)
@@ -59,7 +61,7 @@ class DecodeState:
         T0, B = ctx.shape
         assert B == self.B
         _, _, qkvs = m._run_forward(ctx, None, None, None, need_grad=False, want_logits=True, want_kv=True)
-        H, DH = m.n_head, m.d_head
+        H, DH = m.n_head, m._DHp
         for i, qkv in enumerate(qkvs):
             kv = qkv.view(T0, B, 3, H, DH)
             self.kc[i, :, :, :T0].copy_(kv[:, :, 1].permute(1, 2, 0, 3))
@@ -101,10 +103,11 @@ class DecodeState:
         sequences keep their previous content -- they may still be needed for a re-draw, quirk Q5)."""
         m = self.model
         dev = tokens.device
-        B, L, H, DH, D = self.B, m.n_layer, m.n_head, m.d_head, m.d_model
+        B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
         HD = H * DH
-        h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight)
-        scale = 1.0 / math.sqrt(DH)
+        h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight, ld=D)
+        scale = m.attn_scale
+        u, vb = m._uv()
         for i in range(L):
             w = m._weights(i)
             lay = m.layers[i]
@@ -112,21 +115,20 @@ class DecodeState:
             call("commu_decode_kv_append", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
                  _p(self.klen), _p(active), B, self.Lmax, H, HD, _s())
             call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
-                 _p(self.rd[i]), self.rd[i].stride(0), _p(m.r_w_bias), _p(m.r_r_bias), _p(self.klen), _p(active),
+                 _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
                  _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, _s())
             z1 = ops.gemm_nt(self.vec, w["o"], resid=h)
             a, _, _ = ops.layernorm_fwd(z1, lay.dec_attn.layer_norm.weight, lay.dec_attn.layer_norm.bias)
-            hid = ops.gemm_nt(a, w["w1"], bias=lay.pos_ff.CoreNet[0].bias, relu=True)
-            z2 = ops.gemm_nt(hid, w["w2"], bias=lay.pos_ff.CoreNet[3].bias, resid=a)
+            hid = ops.gemm_nt(a, w["w1"], bias=w["b1"], relu=True)
+            z2 = ops.gemm_nt(hid, w["w2"], bias=w["b2"], resid=a)
             h, _, _ = ops.layernorm_fwd(z2, lay.pos_ff.layer_norm.weight, lay.pos_ff.layer_norm.bias)
         call("commu_decode_advance", _p(self.klen), _p(keep), B, self.Lmax, _s())
         if want_logits:
             V = m.n_token
             if active is None:
-                ops.gemm_nt(h, m._bf16_view("word_emb.emb_layers.0.weight", (V, D)), out=self.logits[:, :V],
-                            bias=m.crit.out_layers[0].bias)
+                ops.gemm_nt(h, m._emb_bf16(), out=self.logits[:, :V], bias=m.crit.out_layers[0].bias)
             else:       # only overwrite the rows of the sequences that stepped
-                tmp = ops.gemm_nt(h, m._bf16_view("word_emb.emb_layers.0.weight", (V, D)), bias=m.crit.out_layers[0].bias,
+                tmp = ops.gemm_nt(h, m._emb_bf16(), bias=m.crit.out_layers[0].bias,
                                   out=torch.empty(B, 768, device=dev, dtype=F32)[:, :V])
                 self.logits[:, :V] = torch.where(active.bool()[:, None], tmp, self.logits[:, :V])
         return self.logits

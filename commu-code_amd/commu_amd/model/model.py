@@ -170,9 +170,18 @@ class MemTransformerLM(nn.Module):
         self.r_r_bias = nn.Parameter(torch.Tensor(n_head, d_head))
         if self.clamp_len > 0:
             raise CommuHipError("clamp_len > 0 is not used by the reference configs and is not built")
-        if d_model % 64 or d_inner % 64 or d_head not in (32, 64) or self.n_token > VPAD:
+        if d_model % 4 or d_model > 1024 or d_head > 64 or d_head < 1 or self.n_token > VPAD:
             raise CommuHipError(f"unsupported shape: d_model={d_model} d_inner={d_inner} d_head={d_head} "
-                                "(this build needs d_model, d_inner % 64 == 0 and d_head in {32, 64})")
+                                "(this build needs d_model % 4 == 0, d_model <= 1024 and d_head <= 64)")
+        # Kernel-side dimensions: d_model / d_inner rounded up to 64, d_head to 32 or 64.  When they differ from the
+        # model's (the released config: d_model 500, d_head 50, d_inner 1000) the bf16 weight shadows, biases and
+        # every activation are ZERO-PADDED to them -- zeros contribute nothing to any contraction; the fp32 master
+        # parameters, gradients and the state_dict keep the reference's shapes.
+        self._Dp = (d_model + 63) // 64 * 64
+        self._DIp = (d_inner + 63) // 64 * 64
+        self._DHp = 32 if d_head <= 32 else 64
+        self._padded = (self._Dp, self._DIp, self._DHp) != (d_model, d_inner, d_head)
+        self.attn_scale = 1.0 / math.sqrt(d_head)                      # model.py:216 (true head dimension)
         # gradient delivery: "direct" writes into the flat gradient buffer that p.grad aliases;
         # "autograd" returns the gradients to autograd (compatible with torch DDP hooks).
         self.grad_mode = "direct"
@@ -268,13 +277,16 @@ class MemTransformerLM(nn.Module):
         return fl["g"][off:off + n].view(shape)
 
     def _refresh_shadows(self, cast=True):
-        """bf16 copy of every parameter (same offsets) + transposed bf16 weights for the dX GEMMs."""
+        """bf16 copy of every parameter (same offsets) + transposed bf16 weights for the dX GEMMs.
+        Padded shapes (see __init__): zero-padded bf16 weights / fp32 biases rebuilt from the master copy."""
         fl = self._flat
         if cast:
             ops.cast_bf16(fl["p"], fl["bf16"])
         D, DI, HD, V = self.d_model, self.d_inner, self.n_head * self.d_head, self.n_token
         sh = fl["shadow"]
         dev = fl["dev"]
+        if self._padded:
+            return self._refresh_padded_shadows()
 
         def tr(key, name, shape, pad_cols=None):
             w = self._bf16_view(name, shape)
@@ -290,16 +302,93 @@ class MemTransformerLM(nn.Module):
             tr(f"w1_t{i}", pre + "pos_ff.CoreNet.0.weight", (DI, D))
             tr(f"w2_t{i}", pre + "pos_ff.CoreNet.3.weight", (D, DI))
 
+    # crop / pad specification of a 2-D parameter: rows = rg groups of rt (padded to rp), cols = cg groups of ct
+    # (padded to cp).  Head-structured dimensions (q|k|v thirds x heads) pad every head separately.
+    def _spec(self, kind):
+        D, DI, H, DH, V = self.d_model, self.d_inner, self.n_head, self.d_head, self.n_token
+        Dp, DIp, DHp = self._Dp, self._DIp, self._DHp
+        return {"qkv": (3 * H, DH, DHp, 1, D, Dp), "kv": (2 * H, DH, DHp, 1, D, Dp), "o": (1, D, Dp, H, DH, DHp),
+                "r": (H, DH, DHp, 1, D, Dp), "w1": (1, DI, DIp, 1, D, Dp), "w2": (1, D, Dp, 1, DI, DIp),
+                "E": (1, V, V, 1, D, Dp), "Egrad": (1, V, VPAD, 1, D, Dp)}[kind]
+
+    def _refresh_padded_shadows(self):
+        fl = self._flat
+        sh, dev = fl["shadow"], fl["dev"]
+        H, DH, DHp = self.n_head, self.d_head, self._DHp
+
+        pmap = dict(self.named_parameters())
+
+        def fp32(name):
+            return pmap[name].data
+
+        def padw(key, name, kind, transpose_key=None, tcols=None):
+            rg, rt, rp, cg, ct, cp = self._spec(kind)
+            if key not in sh:
+                sh[key] = torch.zeros(rg * rp, cg * cp, device=dev, dtype=BF16)
+            sh[key].view(rg, rp, cg, cp)[:, :rt, :, :ct].copy_(fp32(name).view(rg, rt, cg, ct))
+            if transpose_key is not None:
+                if transpose_key not in sh:
+                    sh[transpose_key] = torch.zeros(cg * cp, rg * rp if tcols is None else tcols, device=dev, dtype=BF16)
+                ops.transpose_to_bf16(sh[key], sh[transpose_key][:, :rg * rp])
+
+        def padv(key, name, groups, true, pad):
+            if key not in sh:
+                sh[key] = torch.zeros(groups * pad, device=dev, dtype=F32)
+            sh[key].view(groups, pad)[:, :true].copy_(fp32(name).reshape(groups, true))
+        padw("E", "word_emb.emb_layers.0.weight", "E", "Et", VPAD)
+        padv("u", "r_w_bias", H, DH, DHp)
+        padv("vb", "r_r_bias", H, DH, DHp)
+        for i in range(self.n_layer):
+            pre = f"layers.{i}."
+            padw(f"qkv{i}", pre + "dec_attn.qkv_net.weight", "qkv", f"qkv_t{i}")
+            padw(f"o{i}", pre + "dec_attn.o_net.weight", "o", f"o_t{i}")
+            padw(f"r{i}", pre + "dec_attn.r_net.weight", "r")
+            padw(f"w1{i}", pre + "pos_ff.CoreNet.0.weight", "w1", f"w1_t{i}")
+            padw(f"w2{i}", pre + "pos_ff.CoreNet.3.weight", "w2", f"w2_t{i}")
+            padv(f"b1{i}", pre + "pos_ff.CoreNet.0.bias", 1, self.d_inner, self._DIp)
+            padv(f"b2{i}", pre + "pos_ff.CoreNet.3.bias", 1, self.d_model, self._Dp)
+
     # ------------------------------------------------------------------ forward schedule
     def _weights(self, i):
+        """bf16 GEMM operands and fp32 biases of layer i at the kernel-side (possibly padded) shapes."""
         D, DI, HD = self.d_model, self.d_inner, self.n_head * self.d_head
         pre = f"layers.{i}."
+        lay = self.layers[i]
+        if self._padded:
+            sh = self._flat["shadow"]
+            return {"qkv": sh[f"qkv{i}"], "o": sh[f"o{i}"], "r": sh[f"r{i}"], "w1": sh[f"w1{i}"], "w2": sh[f"w2{i}"],
+                    "b1": sh[f"b1{i}"], "b2": sh[f"b2{i}"]}
         bv = self._bf16_view
         return {"qkv": bv(pre + "dec_attn.qkv_net.weight", (3 * HD, D)),
                 "o": bv(pre + "dec_attn.o_net.weight", (D, HD)),
                 "r": bv(pre + "dec_attn.r_net.weight", (HD, D)),
                 "w1": bv(pre + "pos_ff.CoreNet.0.weight", (DI, D)),
-                "w2": bv(pre + "pos_ff.CoreNet.3.weight", (D, DI))}
+                "w2": bv(pre + "pos_ff.CoreNet.3.weight", (D, DI)),
+                "b1": lay.pos_ff.CoreNet[0].bias, "b2": lay.pos_ff.CoreNet[3].bias}
+
+    def _emb_bf16(self):
+        """[V, Dp] bf16 embedding / output-layer weight."""
+        if self._padded:
+            return self._flat["shadow"]["E"]
+        return self._bf16_view("word_emb.emb_layers.0.weight", (self.n_token, self.d_model))
+
+    def _uv(self):
+        """fp32 r_w_bias, r_r_bias as [H * DHp]."""
+        if self._padded:
+            sh = self._flat["shadow"]
+            return sh["u"], sh["vb"]
+        return self.r_w_bias, self.r_r_bias
+
+    def _mems_in(self, mems):
+        """Memory tensor [L+1, M, B, D] -> kernel-side [L+1, M, B, Dp] (zero padded)."""
+        if not self._padded or mems is None or mems.numel() == 0 or mems.shape[-1] == self._Dp:
+            return mems
+        Lp, M, B, D = mems.shape
+        if mems.dtype == BF16 and mems.stride() == (M * B * self._Dp, B * self._Dp, self._Dp, 1):
+            return torch.as_strided(mems, (Lp, M, B, self._Dp), mems.stride())      # our own padded storage
+        out = torch.zeros(Lp, M, B, self._Dp, device=mems.device, dtype=BF16)
+        out[..., :D].copy_(mems)
+        return out
 
     def _run_forward(self, data, target, reset, mems, need_grad, want_logits=False, want_kv=False):
         fl = self._ensure_flat()
@@ -307,8 +396,10 @@ class MemTransformerLM(nn.Module):
         if not data.is_cuda:
             raise CommuHipError("inputs must be GPU tensors (no CPU fallback)")
         T, B = data.shape
-        D, DI, H, DH, L, V = self.d_model, self.d_inner, self.n_head, self.d_head, self.n_layer, self.n_token
+        # kernel-side (possibly zero-padded) dimensions; Dt = the model's d_model (LayerNorm, embedding scale)
+        Dt, D, DI, H, DH, L, V = self.d_model, self._Dp, self._DIp, self.n_head, self._DHp, self.n_layer, self.n_token
         HD = H * DH
+        mems = self._mems_in(mems)
         M = 0 if mems is None or mems.numel() == 0 else mems.shape[1]
         K = T + M
         TB = T * B
@@ -327,8 +418,8 @@ class MemTransformerLM(nn.Module):
         def ss(site):
             return ops.site_seed(seed, site)
 
-        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight, drop_p=p, drop_seed=ss(0))     # K1
-        pd = ops.posemb(self.pos_emb.inv_freq, K, D, drop_p=p, drop_seed=ss(1))                      # K2 (distance order)
+        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight, drop_p=p, drop_seed=ss(0), ld=D)     # K1
+        pd = ops.posemb(self.pos_emb.inv_freq, K, Dt, drop_p=p, drop_seed=ss(1), ld=D)               # K2 (distance order)
         hids = [h]
         if need_grad:
             sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
@@ -336,7 +427,7 @@ class MemTransformerLM(nn.Module):
             sv.p, sv.patt, sv.seed = p, patt, seed
             for k in ("h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1", "rs1", "a", "hid", "z2", "mu2", "rs2"):
                 setattr(sv, k, [])
-        u, vb = self.r_w_bias, self.r_r_bias
+        u, vb = self._uv()
         h_out = None
         kv_out = []
         for i in range(L):
@@ -353,12 +444,11 @@ class MemTransformerLM(nn.Module):
             rd = ops.gemm_nt(pd, w["r"])                                         # K5
             vec, lse, qs = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
                                            T, M, B, H, DH, bool(self.same_length), int(self.mem_len),
-                                           save_q=need_grad, drop_p=patt, drop_seed=ss(s0))    # K6
+                                           save_q=need_grad, drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale)    # K6
             z1 = ops.gemm_nt(vec, w["o"], resid=h, drop_p=p, drop_seed=ss(s0 + 1))             # K7
             a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)
-            hid = ops.gemm_nt(a, w["w1"], bias=lay[i].pos_ff.CoreNet[0].bias, relu=True, drop_p=p,
-                              drop_seed=ss(s0 + 2))                                            # K8
-            z2 = ops.gemm_nt(hid, w["w2"], bias=lay[i].pos_ff.CoreNet[3].bias, resid=a, drop_p=p, drop_seed=ss(s0 + 3))
+            hid = ops.gemm_nt(a, w["w1"], bias=w["b1"], relu=True, drop_p=p, drop_seed=ss(s0 + 2))   # K8
+            z2 = ops.gemm_nt(hid, w["w2"], bias=w["b2"], resid=a, drop_p=p, drop_seed=ss(s0 + 3))
             if i == L - 1 and p > 0:          # final `self.drop(core_out)` (model.py:601) as a second LN output
                 h_out = torch.empty(TB, D, device=dev, dtype=BF16)
             y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias,
@@ -376,8 +466,7 @@ class MemTransformerLM(nn.Module):
 
         new_mems = self._update_mems(hids, mems, M, T, B)                        # K9
         logits = torch.empty(TB, VPAD, device=dev, dtype=F32)                    # K10 / K14
-        ops.gemm_nt(h_out, self._bf16_view("word_emb.emb_layers.0.weight", (V, D)), out=logits[:, :V],
-                    bias=self.crit.out_layers[0].bias)
+        ops.gemm_nt(h_out, self._emb_bf16(), out=logits[:, :V], bias=self.crit.out_layers[0].bias)
         if want_logits:
             return logits.view(T, B, VPAD)[:, :, :V], new_mems, (kv_out if want_kv else None)
         tgt = target.contiguous().view(-1)
@@ -393,15 +482,17 @@ class MemTransformerLM(nn.Module):
             end = M + T
             beg = max(0, end - self.mem_len)
             n = end - beg
-            out = torch.empty(len(hids), n, B, self.d_model, device=hids[0].device, dtype=BF16)
+            Dp = self._Dp
+            out = torch.empty(len(hids), n, B, Dp, device=hids[0].device, dtype=BF16)
             for i, hcur in enumerate(hids):
-                hv = hcur.view(T, B, self.d_model)
+                hv = hcur.view(T, B, Dp)
                 if beg >= M:
                     out[i].copy_(hv[beg - M:])
                 else:
                     out[i, :M - beg].copy_(mems[i][beg:])
                     out[i, M - beg:].copy_(hv)
-            return out
+            # (padded shapes: the caller sees the reference's [L+1, n, B, d_model]; the view keeps the padded storage)
+            return out[..., :self.d_model] if self._padded else out
 
     # ------------------------------------------------------------------ backward schedule
     def _run_backward(self, sv, dloss):
@@ -431,14 +522,18 @@ class MemTransformerLM(nn.Module):
             return G[gname[name]:gname[name] + n].view(shape)
 
         T, M, B = sv.T, sv.M, sv.B
-        D, DI, H, DH, L, V = self.d_model, self.d_inner, self.n_head, self.d_head, self.n_layer, self.n_token
-        HD, K, TB = H * DH, T + M, T * B
+        # Dt/DIt/DHt: the model's (state_dict) dimensions; D/DI/DH: kernel-side, possibly zero-padded
+        Dt, DIt, DHt = self.d_model, self.d_inner, self.d_head
+        D, DI, H, DH, L, V = self._Dp, self._DIp, self.n_head, self._DHp, self.n_layer, self.n_token
+        HD, HDt, K, TB = H * DH, H * DHt, T + M, T * B
+        pad = self._padded
+        spec = self._spec if pad else (lambda kind: None)
         sh = fl["shadow"]
         g = dloss.reshape(-1).to(F32)
         dlogits = ops.ce_bwd(sv.logits, sv.target, sv.ce_lse, g, V)             # [TB, 768] bf16, pad cols 0
         ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)))
-        gE = gv("word_emb.emb_layers.0.weight", (V, D))
-        self._tn_acc(dlogits, sv.hL, gE, rows=V)
+        gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
+        self._tn_acc(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))
         p, patt = sv.p, sv.patt
         inv_keep = 1.0 / (1.0 - p)
 
@@ -446,7 +541,11 @@ class MemTransformerLM(nn.Module):
             return ops.site_seed(sv.seed, site)
 
         dy = ops.gemm_nt(dlogits, sh["Et"], drop_p=p, drop_seed=ss(2))           # [TB, D] (through the final dropout)
-        gu, gvb = gv("r_w_bias", (HD,)), gv("r_r_bias", (HD,))
+        gu, gvb = gv("r_w_bias", (HDt,)), gv("r_r_bias", (HDt,))
+        if pad:                       # the kernels accumulate [H, DHp] rows; cropped into the gradients at the end
+            gu_t, gvb_t = gu, gvb
+            gu, gvb = torch.zeros(HD, device=dev, dtype=F32), torch.zeros(HD, device=dev, dtype=F32)
+        u_k, vb_k = self._uv()
         for i in range(L - 1, -1, -1):
             pre = f"layers.{i}."
             lay = self.layers[i]
@@ -456,37 +555,37 @@ class MemTransformerLM(nn.Module):
                                           dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3))
             if dz2m is None:
                 dz2m = dz2
-            ops.colsum(part[:, 0], gv(pre + "pos_ff.layer_norm.weight", (D,)))
-            ops.colsum(part[:, 1], gv(pre + "pos_ff.layer_norm.bias", (D,)))
-            ops.colsum(part[:, 2], gv(pre + "pos_ff.CoreNet.3.bias", (D,)))
-            self._tn_acc(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (D, DI)))
+            ops.colsum(part[:, 0], gv(pre + "pos_ff.layer_norm.weight", (Dt,)))
+            ops.colsum(part[:, 1], gv(pre + "pos_ff.layer_norm.bias", (Dt,)))
+            ops.colsum(part[:, 2], gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)))
+            self._tn_acc(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
             dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
-            self._tn_acc(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DI, D)))
-            ops.colsum(dhid, gv(pre + "pos_ff.CoreNet.0.bias", (DI,)))
+            self._tn_acc(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
+            ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
                                           dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1))
             if dz1m is None:
                 dz1m = dz1
-            ops.colsum(part[:, 0], gv(pre + "dec_attn.layer_norm.weight", (D,)))
-            ops.colsum(part[:, 1], gv(pre + "dec_attn.layer_norm.bias", (D,)))
-            self._tn_acc(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (D, HD)))
+            ops.colsum(part[:, 0], gv(pre + "dec_attn.layer_norm.weight", (Dt,)))
+            ops.colsum(part[:, 1], gv(pre + "dec_attn.layer_norm.bias", (Dt,)))
+            self._tn_acc(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]
             dqkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
             if M > 0:
                 dqkv[:M * B, :HD].zero_()
             drd = torch.empty(K, HD, device=dev, dtype=F32)
-            ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], self.r_w_bias,
-                            self.r_r_bias, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
+            ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], u_k,
+                            vb_k, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
-                            drop_p=patt, drop_seed=ss(s0))
-            self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HD, D)))
-            gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HD, D))
-            self._tn_acc(dqkv[M * B:], sv.h[i], gW)
+                            drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale)
+            self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HDt, Dt)), crop=spec("r"))
+            gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
+            self._tn_acc(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))
             if M > 0:
-                self._tn_acc(dqkv[:M * B, HD:], sv.cat[i], gW[HD:])
+                self._tn_acc(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
             hook = getattr(self, "grad_ready_hook", None)
             if hook is not None and direct:
@@ -495,12 +594,17 @@ class MemTransformerLM(nn.Module):
                 hi = gname[f"layers.{i + 1}.dec_attn.qkv_net.weight"] if i + 1 < L else gname["crit.out_layers.0.bias"]
                 hook(G, lo, hi)
         ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0))
+        if pad:
+            gu_t.view(H, DHt).add_(gu.view(H, DH)[:, :DHt])
+            gvb_t.view(H, DHt).add_(gvb.view(H, DH)[:, :DHt])
         if direct:
             return tuple(None for _ in params)
         return tuple(G[off:off + p.numel()].view(p.shape) for p, off in zip(params, fl["offs"]))
 
-    def _tn_acc(self, dY, Xa, gW, rows=None):
-        """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads."""
+    def _tn_acc(self, dY, Xa, gW, rows=None, crop=None):
+        """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads.
+        crop = (rg, rt, rp, cg, ct, cp): the product has the padded shape [rg*rp, cg*cp]; its [rt, ct] blocks are
+        added to gW [rg*rt, cg*ct]."""
         N = dY.shape[1]
         Kc = Xa.shape[1]
         M = dY.shape[0]
@@ -510,5 +614,12 @@ class MemTransformerLM(nn.Module):
         if fl.get("slabs") is None or fl["slabs"].numel() < need:
             fl["slabs"] = torch.empty(need, device=fl["dev"], dtype=F32)
         ops.gemm_tn_raw(dY, Xa, fl["slabs"], ns)
+        if crop is not None:
+            rg, rt, rp, cg, ct, cp = crop
+            assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)
+            tmp = torch.empty(N * Kc, device=fl["dev"], dtype=F32)
+            ops.reduce_slabs(tmp, fl["slabs"], N * Kc, ns, N * Kc, False, 1.0)
+            gW.view(rg, rt, cg, ct).add_(tmp.view(rg, rp, cg, cp)[:, :rt, :, :ct])
+            return
         nrows = N if rows is None else rows
         ops.reduce_slabs(gW, fl["slabs"], nrows * Kc, ns, N * Kc, True, 1.0)

@@ -159,12 +159,13 @@ def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate, alpha=1.0):
     return dst
 
 
-def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0):
+def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0, ld=None):
+    """ld > D: rows are padded to ld columns (zero-padding contract of commu_hip.h)."""
     ntok = tok.numel()
     D = E.shape[1]
     assert tok.dtype == torch.int64 and E.dtype == F32 and E.is_contiguous() and tok.is_contiguous()
     if out is None:
-        out = torch.empty(ntok, D, device=E.device, dtype=BF16)
+        out = torch.empty(ntok, D if ld is None else ld, device=E.device, dtype=BF16)
     call("commu_embed_fwd", _p(tok), _p(E), _p(out), out.stride(0), ntok, D, math.sqrt(D), int(drop_seed),
          float(drop_p), _s())
     return out
@@ -177,16 +178,17 @@ def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0):
     return dE
 
 
-def posemb(inv_freq, K, D, out=None, drop_p=0.0, drop_seed=0):
+def posemb(inv_freq, K, D, out=None, drop_p=0.0, drop_seed=0, ld=None):
     if out is None:
-        out = torch.empty(K, D, device=inv_freq.device, dtype=BF16)
+        out = torch.empty(K, D if ld is None else ld, device=inv_freq.device, dtype=BF16)
     call("commu_posemb_fwd", _p(inv_freq), _p(out), out.stride(0), K, D, int(drop_seed), float(drop_p), _s())
     return out
 
 
 def layernorm_fwd(z, gamma, beta, y=None, mean=None, rstd=None, eps=1e-5, y_drop=None, drop_p=0.0, drop_seed=0):
-    """y = LN(z); optionally also y_drop = dropout(y) (second output)."""
-    rows, D = z.shape
+    """y = LN(z) over the first D = gamma.numel() columns (wider rows: zero-padding contract); optionally also
+    y_drop = dropout(y) (second output)."""
+    rows, D = z.shape[0], gamma.numel()
     y = torch.empty_like(z) if y is None else y
     mean = torch.empty(rows, device=z.device, dtype=F32) if mean is None else mean
     rstd = torch.empty(rows, device=z.device, dtype=F32) if rstd is None else rstd
@@ -197,8 +199,8 @@ def layernorm_fwd(z, gamma, beta, y=None, mean=None, rstd=None, eps=1e-5, y_drop
 
 def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, drop_p=0.0, drop_seed=0):
     """Returns (dz, part) with part [nblk, 3, D]: partial column sums of dy*xhat, dy, dz (or of
-    dz_masked = dz * keep/(1-p) when that second output is requested)."""
-    rows, D = z.shape
+    dz_masked = dz * keep/(1-p) when that second output is requested).  D = gamma.numel()."""
+    rows, D = z.shape[0], gamma.numel()
     nblk = call("commu_layernorm_bwd_nblocks", rows)
     dz = torch.empty_like(z) if dz is None else dz
     if part is None:
@@ -293,7 +295,8 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem_len, drop_p=0.0, drop_seed=0):
+def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem_len, drop_p=0.0, drop_seed=0,
+               scale=None):
     d = AttnDesc()
     d.drop_p, d.drop_seed = float(drop_p), int(drop_seed)
     d.q, d.k, d.v, d.rd = q.data_ptr(), k.data_ptr(), v.data_ptr(), rd.data_ptr()
@@ -306,12 +309,13 @@ def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem
     d.same_length = 1 if same_length else 0
     mask_len = K - mem_len
     d.sshift = (T - mask_len) if mask_len > 0 else T
-    d.scale = 1.0 / math.sqrt(DH)
+    # (scale: 1/sqrt(true d_head) when the head dimension is zero-padded, e.g. 50 -> 64)
+    d.scale = 1.0 / math.sqrt(DH) if scale is None else float(scale)
     return d
 
 
 def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None,
-                save_q=False, drop_p=0.0, drop_seed=0):
+                save_q=False, drop_p=0.0, drop_seed=0, scale=None):
     """q: 2-D view [T*B, H*DH] (row stride ld_qkv), k, v: [(T+M)*B, H*DH]; rd: [K, H*DH] by distance.
     Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], (qu2, qv2) or None)."""
     if out is None:
@@ -321,7 +325,8 @@ def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     qs = None
     if save_q:
         qs = (torch.empty(T * B, H * DH, device=q.device, dtype=BF16), torch.empty(T * B, H * DH, device=q.device, dtype=BF16))
-    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len, drop_p, drop_seed)
+    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len, drop_p, drop_seed,
+                   scale)
     call("commu_relattn_fwd", C.byref(d), _p(out), _p(lse), _p(qs[0]) if qs else None, _p(qs[1]) if qs else None, _s())
     return out, lse, qs
 
@@ -330,7 +335,7 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
-                drd, du, dvb, drop_p=0.0, drop_seed=0):
+                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
     drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
     dev = q.device
@@ -357,7 +362,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     tri_B, tri_M = (B, M) if band else (0, 0)
     dq_ac = torch.empty(T * B, HD, device=dev, dtype=BF16)
     du_part = torch.empty(B * QT, HD, device=dev, dtype=F32)
-    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len, drop_p, drop_seed)
+    d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, o.stride(0), same_length, mem_len, drop_p, drop_seed,
+                   scale)
     e = AttnBwdDesc()
     e.dout, e.lse, e.delta = dout.data_ptr(), lse.data_ptr(), delta.data_ptr()
     e.qu2, e.qv2 = qu2.data_ptr(), qv2.data_ptr()

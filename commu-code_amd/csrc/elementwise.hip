@@ -17,7 +17,9 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
     const int lane = threadIdx.x & 63;
     const float* src = E + (size_t)tok[m] * D;
     bf16* dst = out + (size_t)m * ldo;
-    for (int c = lane * 4; c < D; c += 256) {
+    const int Dz = min(ldo, (D + 63) & ~63);          // zero-padding contract: columns [D, Dz) are written as 0
+    for (int c = lane * 4; c < Dz; c += 256) {
+        if (c >= D) { *(bf16x4*)(dst + c) = (bf16x4){0, 0, 0, 0}; continue; }
         f32x4 v = *(const f32x4*)(src + c);
         bf16x4 o;
 #pragma unroll
@@ -89,6 +91,8 @@ __global__ void posemb_kernel(const float* __restrict__ inv_freq, bf16* __restri
     }
     out[(size_t)d * ld + i] = f2bf(sv);
     out[(size_t)d * ld + half + i] = f2bf(cv);
+    const int Dz = min(ld, (D + 63) & ~63);
+    for (int c = D + i; c < Dz; c += half) out[(size_t)d * ld + c] = f2bf(0.f);      // zero padding [D, Dz)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -103,6 +107,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    // zero-padding contract (D % 4 == 0): columns [D, Dz), Dz = roundup(D, 64) clipped to the row pitch, are
+    // padding -- ignored on input, written as 0 on output.  A 4-element group is wholly valid or wholly padding.
+    const int Dz = min(ldy, (D + 63) & ~63);
     float x[LN_MAXC][8];
     float s = 0.f;
 #pragma unroll
@@ -110,8 +117,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
         const int col = lane * 8 + 512 * c;
         if (col < D) {
             bf16x8 v = ld_bf16x8(z + (size_t)row * ldz + col);
+            const bool hi = col + 4 < D;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { x[c][e] = bf2f(v[e]); s += x[c][e]; }
+            for (int e = 0; e < 8; ++e) { x[c][e] = (e < 4 || hi) ? bf2f(v[e]) : 0.f; s += x[c][e]; }
         }
     }
     const float mu = wave_sum(s) / (float)D;
@@ -120,27 +128,33 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     for (int c = 0; c < LN_MAXC; ++c) {
         const int col = lane * 8 + 512 * c;
         if (col < D) {
+            const bool hi = col + 4 < D;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = x[c][e] - mu; q += d * d; }
+            for (int e = 0; e < 8; ++e) { const float d = x[c][e] - mu; q += (e < 4 || hi) ? d * d : 0.f; }
         }
     }
     const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
         const int col = lane * 8 + 512 * c;
         if (col < D) {
-            const f32x4 g0 = *(const f32x4*)(gamma + col), g1 = *(const f32x4*)(gamma + col + 4);
-            const f32x4 b0 = *(const f32x4*)(beta + col), b1 = *(const f32x4*)(beta + col + 4);
+            const bool hi = col + 4 < D;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 g0 = *(const f32x4*)(gamma + col), g1 = hi ? *(const f32x4*)(gamma + col + 4) : z4;
+            const f32x4 b0 = *(const f32x4*)(beta + col), b1 = hi ? *(const f32x4*)(beta + col + 4) : z4;
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 x[c][e] = (x[c][e] - mu) * rs * g0[e] + b0[e];
-                x[c][4 + e] = (x[c][4 + e] - mu) * rs * g1[e] + b1[e];
+                x[c][4 + e] = hi ? (x[c][4 + e] - mu) * rs * g1[e] + b1[e] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(x[c][e]);
             st_bf16x8(y + (size_t)row * ldy + col, o);
+        } else if (col < Dz) {
+            st_bf16x8(y + (size_t)row * ldy + col, zero8);
         }
     }
     if (ydrop != nullptr) {
@@ -148,12 +162,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
         for (int c = 0; c < LN_MAXC; ++c) {
             const int col = lane * 8 + 512 * c;
             if (col < D) {
+                const bool hi = col + 4 < D;
                 bf16x8 od;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    od[e] = f2bf(drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr)
+                    od[e] = f2bf(((e < 4 || hi) && drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr))
                                      ? x[c][e] * drop_scale : 0.f);
                 st_bf16x8(ydrop + (size_t)row * ldyd + col, od);
+            } else if (col < min(ldyd, (D + 63) & ~63)) {
+                st_bf16x8(ydrop + (size_t)row * ldyd + col, zero8);
             }
         }
     }
@@ -172,10 +189,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     __shared__ float red[4][3][512 * NC];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float ag[NC][8], ab[NC][8], az[NC][8], gm[NC][8];
-    bool act[NC];
+    bool act[NC], hi[NC], padc[NC];          // chunk has valid columns / its upper 4 are valid / pure padding to zero
+    const int Dz = min(lddz, (D + 63) & ~63);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         act[c] = lane * 8 + 512 * c < D;
+        hi[c] = lane * 8 + 512 * c + 4 < D;
+        padc[c] = !act[c] && lane * 8 + 512 * c < Dz;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             ag[c][e] = ab[c][e] = az[c][e] = 0.f;
@@ -208,8 +228,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float d = bf2f(vd[c][e]);
-                xh[c][e] = act[c] ? (bf2f(vz[c][e]) - mu) * rs : 0.f;
+                const bool ok = act[c] && (e < 4 || hi[c]);
+                const float d = ok ? bf2f(vd[c][e]) : 0.f;
+                xh[c][e] = ok ? (bf2f(vz[c][e]) - mu) * rs : 0.f;
                 gy[c][e] = d * gm[c][e];
                 s1 += gy[c][e];
                 s2 += gy[c][e] * xh[c][e];
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                 bf16x8 o, om;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = rs * (gy[c][e] - m1 - xh[c][e] * m2);
+                    const float v = (e < 4 || hi[c]) ? rs * (gy[c][e] - m1 - xh[c][e] * m2) : 0.f;
                     o[e] = f2bf(v);
                     if (dzm != nullptr) {
                         // gradient w.r.t. the pre-dropout Linear output that fed this LayerNorm
@@ -238,6 +259,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                 }
                 st_bf16x8(dz + (size_t)row * lddz + col, o);
                 if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, om);
+            } else if (padc[c]) {
+                st_bf16x8(dz + (size_t)row * lddz + col, zero8);
+                if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, zero8);
             }
         }
     }
@@ -538,7 +562,9 @@ extern "C" int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, c
                                    void* y_drop, int ldyd, unsigned drop_seed, float drop_p,
                                    hipStream_t stream) {
     if (rows <= 0) return 0;
-    if (D > 1024 || (D % 8) || (ldz % 8) || (ldy % 8)) return -22;
+    const int D8 = (D + 7) & ~7;
+    if (D > 1024 || (D % 4) || (ldz % 8) || (ldy % 8) || ldz < D8 || ldy < D8 || (y_drop != nullptr && ((ldyd % 8) || ldyd < D8)))
+        return -22;
     COMMU_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)z,
                        ldz, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, D, eps, (bf16*)y_drop, ldyd, drop_seed,
                        drop_threshold(drop_p), 1.f / (1.f - drop_p));
@@ -553,7 +579,10 @@ extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int 
                                    float* part, int rows, int D, void* dz_masked, int lddzm,
                                    unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (rows <= 0) return 0;
-    if (D > 1024 || (D % 8)) return -22;
+    const int D8 = (D + 7) & ~7;
+    if (D > 1024 || (D % 4) || (lddy % 8) || (ldz % 8) || (lddz % 8) || lddy < D8 || ldz < D8 || lddz < D8 ||
+        (dz_masked != nullptr && lddzm != lddz))
+        return -22;
     if (D <= 512)
         COMMU_LAUNCH(layernorm_bwd_kernel<1>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
                      (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,

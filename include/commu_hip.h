@@ -68,6 +68,9 @@ int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, co
 int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, size_t stride,
                            int accumulate, float alpha, hipStream_t stream);
 
+/* Zero-padding contract of the row-wise kernels below (embed_fwd, posemb_fwd, layernorm_fwd/bwd): a row may be
+ * wider than its D features (pitch ld > D, D % 4 == 0); columns [D, min(ld, roundup(D, 64))) are PADDING: ignored
+ * on input, written as zeros on output, so the next GEMM can contract over the padded width (d_model 500 -> 512). */
 /* ---- embedding (AdaptiveEmbedding.forward, model.py:409-420) and its gradient */
 /* (drop_p > 0: dropout of the scaled embedding, `core_out = self.drop(word_emb)`, model.py:585;
  *  every dropout in this ABI is the counter-based mask keep(seed, element index)) */

@@ -21,6 +21,9 @@ CONFIGS = [
     ("cfg0_L2_D128_T256", 2, 4, 128, 256, 256, 0, 3, 1),          # configs[0]: reference train.py plumbing case
     ("cfg1_L6_D512_T1024", 6, 8, 512, 1024, 1024, 0, 2, 1),       # configs[1]/[2]: the bench shape
     ("cfg4_L2of12_D1024_T2048_M2048", 2, 16, 1024, 4096, 2048, 2048, 1, 2),   # configs[4]: shape of one layer pair
+    # the reference's released default (config_helper.py:7-10,23-24): d_model 500, 10 heads of 50, d_inner 1000 --
+    # zero-padded to 512 / 64 / 1024 inside the kernels
+    ("default_L6_D500_dh50_T128_M1024", 6, 10, 500, 1000, 128, 1024, 2, 3),
 ]
 
 
@@ -94,3 +97,38 @@ def test_bench_shape_full_batch_trains():
     assert all(math.isfinite(x) for x in losses), losses
     assert abs(losses[0] - math.log(729)) < 0.3, losses           # random init: ~uniform over the vocabulary
     assert losses[-1] < losses[1], losses                         # lr(0) = 0 (quirk Q7): step 0 does not move
+
+
+def test_default_config_generate_and_kv_cache_decode_dh50():
+    """forward_generate and the K/V-cache decode step at the released head shape (d_head 50 -> padded 64):
+    logits vs the oracle, and the cached single-token step vs the full forward."""
+    from commu_amd.generate import DecodeState
+    L, H, D, DI = 2, 10, 500, 1000
+    model, cfg, s, params = build(L, H, D, DI, 1, 4146, seed=21)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    g = torch.Generator().manual_seed(8)
+    B = 3
+    ctx = torch.randint(1, 729, (12, B), generator=g)
+    with torch.no_grad():
+        ref_logits, ref_mems = X.forward_generate(params, s, ctx, None, 4146, True)
+    logits, mems = model.forward_generate(ctx.to(DEV), None)
+    assert tuple(mems.shape) == tuple(ref_mems.shape)
+    err = (logits.float().cpu() - ref_logits).abs().max() / ref_logits.abs().max()
+    assert float(err) < 2e-2, float(err)
+    assert float((mems.float().cpu() - ref_mems).abs().max() / ref_mems.abs().max()) < 3e-2
+    # a second call fed with the returned (view of padded) memory
+    nxt = torch.randint(1, 729, (1, B), generator=g)
+    with torch.no_grad():
+        ref2, _ = X.forward_generate(params, s, nxt, ref_mems, 4146, True)
+    l2, _ = model.forward_generate(nxt.to(DEV), mems)
+    assert float((l2.float().cpu() - ref2).abs().max() / ref2.abs().max()) < 2e-2
+    # K/V cache: prefill 12 tokens, one cached step with the 13th
+    st = DecodeState(model, B, 64)
+    st.prefill(ctx.to(DEV))
+    ones = torch.ones(B, dtype=torch.uint8, device=DEV)
+    lg = st.step(nxt[0].to(DEV), ones, ones)[:, :729]
+    assert float((lg.float().cpu() - ref2[0]).abs().max() / ref2.abs().max()) < 2e-2
+    assert torch.equal(lg.argmax(1).cpu(), ref2[0].argmax(1)) or float(
+        (ref2[0].topk(2, dim=1).values[:, 0] - ref2[0].topk(2, dim=1).values[:, 1]).min()) < 0.05
