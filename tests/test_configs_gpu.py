@@ -132,3 +132,37 @@ def test_default_config_generate_and_kv_cache_decode_dh50():
     assert float((lg.float().cpu() - ref2[0]).abs().max() / ref2.abs().max()) < 2e-2
     assert torch.equal(lg.argmax(1).cpu(), ref2[0].argmax(1)) or float(
         (ref2[0].topk(2, dim=1).values[:, 0] - ref2[0].topk(2, dim=1).values[:, 1]).min()) < 0.05
+
+
+def test_evaluate_same_length_memory_window_vs_oracle():
+    """Trainer.evaluate (train.py:74-110): same_length masks with the longer EVALUATE memory; the memory
+    overflows its window after the second segment, so the same_length shift (model.py:549-568) is exercised."""
+    from commu_amd.train import Trainer
+    L, H, D, DI, T, B = 2, 2, 100, 136, 48, 3
+    model, cfg, s, params = build(L, H, D, DI, T, 0, seed=31)
+    cfg.defrost() if hasattr(cfg, "defrost") else None
+    cfg.EVALUATE.tgt_length, cfg.EVALUATE.mem_length = T, 80
+    g = torch.Generator().manual_seed(12)
+    segs = []
+    for i in range(4):
+        data = torch.randint(1, 729, (T, B), generator=g)
+        target = torch.randint(1, 729, (T, B), generator=g)
+        target[-3:, 1] = 0
+        segs.append((data, target, i == 2, int((target != 0).sum())))       # third segment resets the memory
+
+    def eval_iter():
+        for d, t, r, n in segs:
+            yield d.to(DEV), t.to(DEV), r, n
+    tr = Trainer(model, cfg)
+    tok, nll = tr.evaluate(eval_iter)
+    ref_tok, ref_nll, omems = 0, 0.0, None
+    with torch.no_grad():
+        for d, t, r, n in segs:
+            if r:
+                omems = None
+            loss, omems = X.forward_loss(params, s, d, t, None, omems, 80, True)
+            ref_nll += n * float(loss[t != 0].mean())
+            ref_tok += n
+    assert tok == ref_tok
+    assert abs(nll / tok - ref_nll / ref_tok) < 6e-3, (nll / tok, ref_nll / ref_tok)
+    assert model.training and model.mem_len == cfg.TRAIN.mem_length and model.same_length == cfg.MODEL.same_length
