@@ -254,6 +254,86 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Skinny NT GEMM for the decode step (M <= 64 rows: one token per sequence): C[M, N] = A[M, K] . B[N, K]^T.
+// The work is a single pass over the weights, so the kernel is latency-, not throughput-bound: the tiled
+// kernel's 2-stage pipeline walks K in 8-16 dependent HBM round trips (17 us per GEMM).  Here a workgroup owns
+// 32 output columns, its 4 waves split K, and every wave issues ALL its fragment loads (weights and
+// activations, straight from global memory in MFMA operand layout) before the first MFMA: one round trip.
+// Partial sums meet in LDS; epilogue bias -> ReLU -> residual.
+template <int KSTEPS, bool OUT_F32>          // KSTEPS = K / 128: 32-wide MFMA steps per wave
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(
+    const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
+    int M, int N, const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr, int flags) {
+    __shared__ float red[4][32][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 32;
+    const int k0 = w * KSTEPS * 32 + 8 * g;
+    bf16x8 bfr[2][KSTEPS], af[4][KSTEPS];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const bf16* bp = B + (size_t)min(n0 + 16 * ni + r16, N - 1) * ldb + k0;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) bfr[ni][ks] = ld_bf16x8(bp + 32 * ks);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const bf16* ap = A + (size_t)min(16 * mi + r16, M - 1) * lda + k0;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) af[mi][ks] = ld_bf16x8(ap + 32 * ks);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // every load above is in flight before the first MFMA waits
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(bfr[ni][ks], af[mi][ks], acc[ni][mi]);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[w][(ni * 4 + mi) * 4 + e][lane] = acc[ni][mi][e];
+    __syncthreads();
+    // wave w finishes blocks (ni = w >> 1, mi = 2 (w & 1) + {0, 1}); lane holds C[16 mi + r16][n0 + 16 ni + 4 g + e]
+    const int ni = w >> 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int mi = 2 * (w & 1) + q;
+        const int m = 16 * mi + r16, n = n0 + 16 * ni + 4 * g;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = (ni * 4 + mi) * 4 + e;
+            v[e] = red[0][idx][lane] + red[1][idx][lane] + red[2][idx][lane] + red[3][idx][lane];
+        }
+        if (m >= M || n >= N) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e < N) {
+                if (flags & COMMU_EPI_BIAS) v[e] += bias[n + e];
+                if (flags & COMMU_EPI_RELU) v[e] = fmaxf(v[e], 0.f);
+                if (flags & COMMU_EPI_RESID) v[e] += bf2f(resid[(size_t)m * ldr + n + e]);
+            }
+        }
+        if (OUT_F32) {
+            float* C = (float*)Cv + (size_t)m * ldc + n;
+            if (n + 3 < N) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+            else for (int e = 0; e < 4; ++e) if (n + e < N) C[e] = v[e];
+        } else {
+            bf16* C = (bf16*)Cv + (size_t)m * ldc + n;
+            if (n + 3 < N) *(bf16x4*)C = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            else for (int e = 0; e < 4; ++e) if (n + e < N) C[e] = f2bf(v[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN: out[n, k] (fp32 slab per m-slice) = sum_{m in slice} A[m, n] * B[m, k].
 // Both operands have the contraction index m as their ROW index, so MFMA fragments (8
 // consecutive m per lane) are columns of the staged [32 m][128] LDS images.
@@ -458,6 +538,32 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
                           hipStream_t stream) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (K <= 0 || (K % 32) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
+    if (M <= 64 && batch == 1 && bs.tri_B == 0 && (K % 128) == 0 && K <= 1024 && N >= 32 &&
+        !(flags & (COMMU_EPI_DROPOUT | COMMU_EPI_RELUMASK)) && !getenv("COMMU_GEMM_NOSKINNY")) {
+        dim3 grid((N + 31) / 32);
+#define SK_LAUNCH(KS)                                                                                                \
+    {                                                                                                                \
+        if (flags & COMMU_EPI_OUT_F32)                                                                               \
+            COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, true>), grid, dim3(256), 0, stream, (const bf16*)A, lda,         \
+                         (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);                   \
+        else                                                                                                         \
+            COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, false>), grid, dim3(256), 0, stream, (const bf16*)A, lda,        \
+                         (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);                   \
+    }
+        switch (K / 128) {
+            case 1: SK_LAUNCH(1) break;
+            case 2: SK_LAUNCH(2) break;
+            case 3: SK_LAUNCH(3) break;
+            case 4: SK_LAUNCH(4) break;
+            case 5: SK_LAUNCH(5) break;
+            case 6: SK_LAUNCH(6) break;
+            case 7: SK_LAUNCH(7) break;
+            default: SK_LAUNCH(8) break;
+        }
+#undef SK_LAUNCH
+        COMMU_LAUNCH_CHECK();
+        return 0;
+    }
     const bool narrow = (N <= 64);
     // large M: 256 x 256 (512 threads) for wide outputs, 256 x 128 (256 threads, two workgroups per CU so one's
     // epilogue overlaps the other's main loop) otherwise; 128 x 128 for small problems
