@@ -76,20 +76,29 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const bf16* kb = kc + ((size_t)b * H + h) * Lmax * DH + 8 * sub;
     const bf16* vbp = vc + ((size_t)b * H + h) * Lmax * DH + 8 * sub;
     const bf16* rb = rd + h * DH + 8 * sub;
-    // ---- scores: RPW keys per wave instruction
+    // ---- scores: RPW keys per wave instruction, UNR instructions' loads in flight together (the step is a single
+    // pass over the cache: memory-level parallelism, not arithmetic, sets its speed)
+    constexpr int UNR = 4;
     float mx = -3.0e38f;
-    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW) {
-        const int j = j0 + rowl;
-        const int jc = min(j, n - 1);
-        const bf16x8 kk = ld_bf16x8(kb + (size_t)jc * DH);
-        const bf16x8 r8 = ld_bf16x8(rb + (size_t)((n - 1) - jc) * ld_rd);
-        float s = 0.f;
+    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW * UNR) {
+        bf16x8 kk[UNR], r8[UNR];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kk[e]) + qv[e] * bf2f(r8[e]);
-        s = (LPR == 8) ? oct_sum(s) : (s + dpp_f<0xB1>(s)) + dpp_f<0x4E>(s + dpp_f<0xB1>(s));
-        if (j < n) {
-            if (sub == 0) sS[j] = s;
-            mx = fmaxf(mx, s);
+        for (int u = 0; u < UNR; ++u) {
+            const int jc = min(j0 + 4 * RPW * u + rowl, n - 1);
+            kk[u] = ld_bf16x8(kb + (size_t)jc * DH);
+            r8[u] = ld_bf16x8(rb + (size_t)((n - 1) - jc) * ld_rd);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + 4 * RPW * u + rowl;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kk[u][e]) + qv[e] * bf2f(r8[u][e]);
+            s = (LPR == 8) ? oct_sum(s) : (s + dpp_f<0xB1>(s)) + dpp_f<0x4E>(s + dpp_f<0xB1>(s));
+            if (j < n) {
+                if (sub == 0) sS[j] = s;
+                mx = fmaxf(mx, s);
+            }
         }
     }
     mx = wave_max(mx);
@@ -108,14 +117,19 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
     // ---- P.V: lane accumulates 8 features of the keys it visits
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW) {
-        const int j = j0 + rowl;
-        if (j < n) {
-            const float p = sS[j];
-            const bf16x8 v8 = ld_bf16x8(vbp + (size_t)j * DH);
+    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW * UNR) {
+        bf16x8 v8[UNR];
+        float p[UNR];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += p * bf2f(v8[e]);
+        for (int u = 0; u < UNR; ++u) {
+            const int j = j0 + 4 * RPW * u + rowl;
+            v8[u] = ld_bf16x8(vbp + (size_t)min(j, n - 1) * DH);
+            p[u] = (j < n) ? sS[j] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p[u] * bf2f(v8[u][e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) sO[w][rowl][8 * sub + e] = acc[e];
