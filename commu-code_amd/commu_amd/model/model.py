@@ -580,7 +580,8 @@ class MemTransformerLM(nn.Module):
             ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], u_k,
                             vb_k, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
-                            drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale)
+                            drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
+                            scratch=fl.setdefault("attn_scratch", {}))
             self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HDt, Dt)), crop=spec("r"))
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
             self._tn_acc(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))

@@ -335,7 +335,7 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
-                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None):
+                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
     drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
     dev = q.device
@@ -347,11 +347,20 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
     call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
     ld_dsk = round_up(K, 32)
-    # dS by distance is lower-triangular (d <= i + M).  Without same_length / reset masks the kernel writes the
-    # triangle plus a wedge of zeros and the two GEMMs below only visit the band: no 1 GB zero-fill per layer,
-    # half the GEMM work.  Wedge >= what a GEMM row tile (128 rows) / output tile (128 columns) can overhang.
+    # dS by distance is lower-triangular (d <= i + M).  Without same_length / reset masks the two GEMMs below only
+    # visit the band (half the work) and the kernel only writes the triangle.  What lies right of the causal edge
+    # must read as zero: either the kernel also writes a wedge of zeros as wide as a GEMM tile can overhang
+    # (fresh, uninitialised scratch) or the caller keeps ONE zero-initialised scratch per shape alive
+    # (`scratch` dict, used by the model): nothing ever writes beyond the triangle, so it stays zero -- no 1 GB
+    # fill per layer and no wedge.
     band = (not same_length) and reset is None
-    if band:
+    key = (T, M, B, H, ld_dsk, str(dev))
+    if band and scratch is not None and not POISON_SCRATCH:
+        if scratch.get("key") != key:
+            scratch["key"], scratch["dsk"] = key, None          # drop the old buffer before allocating the new one
+            scratch["dsk"] = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
+        dsk, wedge = scratch["dsk"], 0
+    elif band:
         wedge = 136 + (128 + B - 1) // B
         dsk = torch.empty(H, T * B, ld_dsk, device=dev, dtype=BF16)
         if POISON_SCRATCH:
