@@ -521,6 +521,29 @@ class MemTransformerLM(nn.Module):
                 n *= s
             return G[gname[name]:gname[name] + n].view(shape)
 
+        # Weight-gradient GEMMs (dW = dY^T X) are off the critical path of backward: they only feed the optimiser.
+        # They run on a SIDE stream, ordered after the kernels that produced their operands, so they fill the
+        # tails of the attention / dX kernels on the main stream; joined before the gradients are consumed.
+        main = torch.cuda.current_stream()
+        side = fl.get("wgrad_stream") if getattr(self, "wgrad_side_stream", True) else None
+        if side is None and getattr(self, "wgrad_side_stream", True):
+            side = fl["wgrad_stream"] = torch.cuda.Stream(device=dev)
+        keep = []          # operands stay referenced until the join: the allocator must not hand them out early
+
+        def wgrad(dY, Xa, gW, rows=None, crop=None):
+            if side is None:
+                return self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
+            keep.extend((dY, Xa))
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
+
+        def join():
+            if side is not None:
+                main.wait_stream(side)
+
         T, M, B = sv.T, sv.M, sv.B
         # Dt/DIt/DHt: the model's (state_dict) dimensions; D/DI/DH: kernel-side, possibly zero-padded
         Dt, DIt, DHt = self.d_model, self.d_inner, self.d_head
@@ -533,7 +556,7 @@ class MemTransformerLM(nn.Module):
         dlogits = ops.ce_bwd(sv.logits, sv.target, sv.ce_lse, g, V)             # [TB, 768] bf16, pad cols 0
         ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)))
         gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
-        self._tn_acc(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))
+        wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))
         p, patt = sv.p, sv.patt
         inv_keep = 1.0 / (1.0 - p)
 
@@ -558,9 +581,9 @@ class MemTransformerLM(nn.Module):
             ops.colsum(part[:, 0], gv(pre + "pos_ff.layer_norm.weight", (Dt,)))
             ops.colsum(part[:, 1], gv(pre + "pos_ff.layer_norm.bias", (Dt,)))
             ops.colsum(part[:, 2], gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)))
-            self._tn_acc(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
+            wgrad(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
             dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
-            self._tn_acc(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
+            wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
             ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
@@ -570,7 +593,7 @@ class MemTransformerLM(nn.Module):
                 dz1m = dz1
             ops.colsum(part[:, 0], gv(pre + "dec_attn.layer_norm.weight", (Dt,)))
             ops.colsum(part[:, 1], gv(pre + "dec_attn.layer_norm.bias", (Dt,)))
-            self._tn_acc(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
+            wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]
             dqkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
@@ -582,18 +605,20 @@ class MemTransformerLM(nn.Module):
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
                             scratch=fl.setdefault("attn_scratch", {}))
-            self._tn_acc(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HDt, Dt)), crop=spec("r"))
+            wgrad(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HDt, Dt)), crop=spec("r"))
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
-            self._tn_acc(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))
+            wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))
             if M > 0:
-                self._tn_acc(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
+                wgrad(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
             hook = getattr(self, "grad_ready_hook", None)
             if hook is not None and direct:
+                join()
                 # every gradient of layer i is final (and enqueued): its slice of the flat buffer may be exchanged
                 lo = gname[pre + "dec_attn.qkv_net.weight"]
                 hi = gname[f"layers.{i + 1}.dec_attn.qkv_net.weight"] if i + 1 < L else gname["crit.out_layers.0.bias"]
                 hook(G, lo, hi)
+        join()                     # (gE also receives the output-layer weight gradient from the side stream)
         ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0))
         if pad:
             gu_t.view(H, DHt).add_(gu.view(H, DH)[:, :DHt])
