@@ -139,29 +139,29 @@ struct Stager {
     static constexpr int CH = COLS / 8;
     static constexpr int N = (ROWS * CH + NTHR - 1) / NTHR;
     static constexpr bool FULL = (ROWS * CH) % NTHR == 0;      // every thread owns N chunks
+    static constexpr int RSTEP = NTHR / CH;                    // tile rows between a thread's consecutive chunks
+    static_assert(NTHR % CH == 0 && (RSTEP % 16 == 0 || N == 1), "chunk n+1 sits RSTEP rows below chunk n, same swizzle");
     bf16x8 reg[N];
-    unsigned goff[N];      // byte offset of this thread's chunk n inside the tile (global side)
-    unsigned loff[N];      // swizzled byte offset inside the LDS tile
+    // One global and one LDS byte offset per thread (chunk 0); chunk n is RSTEP rows further down in both images and
+    // -- RSTEP being a multiple of the swizzle period -- keeps the same swizzled column: no per-chunk offset registers.
+    unsigned goff0, loff0, gstep;
     bool own;              // (partial tiles only) this thread has a chunk in the last pass
     __device__ __forceinline__ void init(unsigned row_stride_bytes, int tid) {
-        own = true;
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const int i = tid + NTHR * n, r = i / CH, c = i % CH;
-            goff[n] = (unsigned)r * row_stride_bytes + (unsigned)c * 16u;
-            loff[n] = (unsigned)(r * COLS + ((c ^ (swz<COLS>(r) & (CH - 1))) << 3)) * 2u;
-            if (!FULL && n == N - 1) own = i < ROWS * CH;
-        }
+        const int r = tid / CH, c = tid % CH;
+        goff0 = (unsigned)r * row_stride_bytes + (unsigned)c * 16u;
+        loff0 = (unsigned)(r * COLS + ((c ^ (swz<COLS>(r) & (CH - 1))) << 3)) * 2u;
+        gstep = (unsigned)RSTEP * row_stride_bytes;
+        own = FULL || (tid + NTHR * (N - 1) < ROWS * CH);
     }
     __device__ __forceinline__ void load(srd_t srd, unsigned tile_off) {
 #pragma unroll
         for (int n = 0; n < N; ++n)      // a thread without a chunk reads far out of range (returns zero, no branch)
-            reg[n] = buf_ld(srd, (FULL || n < N - 1 || own) ? goff[n] + tile_off : 0xFFFFFFF0u);
+            reg[n] = buf_ld(srd, (FULL || n < N - 1 || own) ? goff0 + (unsigned)n * gstep + tile_off : 0xFFFFFFF0u);
     }
     __device__ __forceinline__ void store(bf16* dst) const {
 #pragma unroll
         for (int n = 0; n < N; ++n)
-            if (FULL || n < N - 1 || own) *(bf16x8*)((char*)dst + loff[n]) = reg[n];
+            if (FULL || n < N - 1 || own) *(bf16x8*)((char*)dst + loff0 + (unsigned)(n * RSTEP * COLS * 2)) = reg[n];
     }
 };
 
@@ -285,13 +285,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
         const int j0 = jt * 64;
         if (jt < jt_hi) issue(jt + 1);
 
-        f32x4 s[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[c] = mfma16(qu[ks], frag<DH>(sK, 16 * c + r16, 4 * ks + g), s[c]);
-        }
+        // band product first; its skewed diagonal BD[row][jj] = QR[row][row - jj + 63] becomes the INITIAL value of
+        // the score accumulators, and the QK^T MFMAs accumulate on top (no separate add, 16 fewer live registers)
         f32x4 qr[5];
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
@@ -300,17 +295,22 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], frag<DH>(sR, prow, 4 * ks + g), qr[blk]);
         }
-        // skew: BD[row][jj] = QR[row][row - jj + 63]
+        f32x4 s[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             // named scalars (not an array): `cond ? pm[a] : pm[b]` would be turned into a dynamic index
             // select at the SOURCE lane t (dest lane s < row  <=>  t < row), then one permute per output
             const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
                         t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
-            s[0][reg] += bperm(srcaddr[reg], t0);
-            s[1][reg] += bperm(srcaddr[reg], t1);
-            s[2][reg] += bperm(srcaddr[reg], t2);
-            s[3][reg] += bperm(srcaddr[reg], t3);
+            s[0][reg] = bperm(srcaddr[reg], t0);
+            s[1][reg] = bperm(srcaddr[reg], t1);
+            s[2][reg] = bperm(srcaddr[reg], t2);
+            s[3][reg] = bperm(srcaddr[reg], t3);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[c] = mfma16(qu[ks], frag<DH>(sK, 16 * c + r16, 4 * ks + g), s[c]);
         }
         const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
                                (rst && j0 < M) || (iw_hi >= T);
