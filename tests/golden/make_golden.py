@@ -522,8 +522,79 @@ def g7():
         print("g7 skipped:", repr(e))
 
 
+def g7_cases():
+    """Meta / chord-progression encoding over many seeded inputs (incl. "unknown" fields, 3/4 6/8 12/8 meters,
+    flat / slash / extended chord names, rejected inputs): inputs and the reference's outputs or error class."""
+    import json
+    import random
+    from commu.midi_generator.info_preprocessor import PreprocessTask
+    from commu.preprocessor.utils import constants as C
+    rng = random.Random(7)
+    naturals, sharps, flats = list("ABCDEFG"), ["A#", "C#", "D#", "F#", "G#"], ["Ab", "Bb", "Db", "Eb", "Gb"]
+    base_q = ["", "7", "+", "dim", "m", "m7", "m7b5", "maj7", "sus4"]
+    nat_q = base_q + ["7sus4", "m6", "sus2", "add2", "dim7", "6", "madd2"]
+    flat_q = base_q + ["maj", "dim7", "m6", "7sus4", "sus2", "add2", "6", "madd2"]
+    bad_q = ["9", "mM7", "maj"]                        # not in the vocabulary for the root they are drawn with
+
+    def one_chord():
+        r = rng.random()
+        if r < 0.45:
+            c = rng.choice(naturals) + rng.choice(nat_q)
+        elif r < 0.65:
+            c = rng.choice(sharps) + rng.choice(base_q)
+        elif r < 0.97:
+            c = rng.choice(flats) + rng.choice(flat_q)
+        else:
+            c = rng.choice(sharps) + rng.choice(bad_q)
+        if rng.random() < 0.15:
+            c += "/" + rng.choice(naturals + sharps + flats)
+        if rng.random() < 0.08:
+            c += "(add9)"
+        return c
+    cases = []
+    for n in range(260):
+        ts = rng.choice(list(C.TIME_SIG_MAP))
+        nm = rng.choice([4, 5, 8, 9, 16, 17, 4.0, 8.0, 8, 4, 16, 12, 3])
+        from fractions import Fraction
+        nchord = int((nm - (nm % 4)) * Fraction(ts) * 8) if nm >= 4 else 8
+        prog, cur = [], None
+        for i in range(max(nchord, 1)):
+            if cur is None or rng.random() < 0.3:
+                cur = one_chord()
+            prog.append(cur)
+        if rng.random() < 0.03:
+            prog = prog[:-1]                       # wrong length -> validator error
+        unk = lambda v: C.UNKNOWN if (isinstance(v, str) and rng.random() < 0.06) else v
+        args = dict(output_dir="/tmp/x", bpm=unk(rng.choice([1, 3, 40, 70, 120, 199, 200, 260])),
+                    audio_key=unk(rng.choice(list(C.KEY_MAP) + ["hminor"])),
+                    time_signature=ts, pitch_range=unk(rng.choice(list(C.PITCH_RANGE_MAP))), num_measures=nm,
+                    inst=unk(rng.choice(list(C.INST_MAP) + ["kazoo"])), genre=unk(rng.choice(list(C.GENRE_MAP))),
+                    min_velocity=unk(rng.randrange(1, 127)), max_velocity=unk(rng.randrange(1, 128)),
+                    track_role=unk(rng.choice(list(C.TRACK_ROLE_MAP))), rhythm=unk(rng.choice(list(C.RHYTHM_MAP))),
+                    chord_progression="-".join(prog), num_generate=1, top_k=32, temperature=0.95)
+        rec = {"args": {k: v for k, v in args.items() if k != "output_dir"}}
+        try:
+            t = PreprocessTask()
+            rec["encoded_meta"] = [int(x) for x in t.execute(dict(args))]
+        except Exception as e:
+            rec["meta_error"] = type(e).__name__
+        try:
+            t2 = PreprocessTask()
+            t2.normalize_input_data(dict(args))
+            comp = t2.input_data.chord_token_components
+            rec["chord_token"] = [int(x) for x in comp["chord_token"]]
+            rec["chord_position"] = [int(x) for x in comp["chord_position"]]
+        except Exception as e:
+            rec["chord_error"] = type(e).__name__
+        cases.append(rec)
+    import gzip
+    with gzip.open(os.path.join(HERE, "g7_meta_cases.json.gz"), "wt") as f:
+        json.dump(cases, f)
+    print("g7_cases", len(cases), sum("encoded_meta" in c for c in cases), sum("chord_token" in c for c in cases))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g8o", "g8d", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g7c", "g8o", "g8d", "g9"]
     if "g1" in which:
         g1("mem", 2, 2, 64, 128, 12, 3, 16, False)
         g1("nomem", 2, 2, 64, 128, 12, 3, 0, False)
@@ -538,6 +609,8 @@ if __name__ == "__main__":
         g6()
     if "g7" in which:
         g7()
+    if "g7c" in which:
+        g7_cases()
     if "g8o" in which:
         g8_optim()
     if "g8d" in which:

@@ -124,3 +124,53 @@ def test_synthetic_batch_shape():
     d, t, r, n = synthetic_batch(16, 4, "cpu", seed=1)
     assert d.shape == (16, 4) and n == 64 and int(d.min()) >= 2 and int(d.max()) < 729
     assert torch.equal(d[1:], t[:-1]) and not bool(r.any())
+
+
+def test_meta_and_chord_encoding_vs_reference_cases(golden_dir):
+    """commu_amd.midi_generator.meta against 260 seeded inputs run through the reference's PreprocessTask
+    (tests/golden/make_golden.py g7c): tokens, chord components, and WHICH inputs are rejected."""
+    import gzip
+    import json
+    from commu_amd.midi_generator import meta as MM
+    with gzip.open(os.path.join(golden_dir, "g7_meta_cases.json.gz"), "rt") as f:
+        cases = json.load(f)
+    n_meta = n_chord = 0
+    for c in cases:
+        args = c["args"]
+        try:
+            data = MM.InputData(**args)
+        except (ValueError, TypeError):
+            assert c.get("meta_error") == "ValidationError" or c.get("chord_error") == "ValidationError", args
+            continue
+        if c.get("meta_error") == "ValidationError":
+            # pydantic type validation of the reference (e.g. "unknown" in an int field): not a token-level case
+            continue
+        if "encoded_meta" in c:
+            assert MM.encode_meta(data) == c["encoded_meta"], args
+            n_meta += 1
+        else:
+            with pytest.raises(MM.UnprocessableMidiError):
+                MM.encode_meta(data)
+        if "chord_token" in c:
+            comp = data.chord_token_components
+            assert comp["chord_token"] == c["chord_token"] and comp["chord_position"] == c["chord_position"], args
+            n_chord += 1
+        elif c.get("chord_error") == "KeyError":
+            with pytest.raises(KeyError):
+                data.chord_token_components
+    assert n_meta > 150 and n_chord > 100
+
+
+def test_meta_readme_example(golden_dir):
+    from commu_amd.midi_generator.meta import PreprocessTask
+    z = np.load(os.path.join(golden_dir, "g7_meta.npz"))
+    prog = "-".join(["Am"] * 8 + ["G"] * 8 + ["F"] * 8 + ["E"] * 8) * 1
+    prog = prog + "-" + prog
+    t = PreprocessTask()
+    enc = t.execute(dict(bpm=70, audio_key="aminor", time_signature="4/4", pitch_range="mid_high", num_measures=8.0,
+                         inst="acoustic_piano", genre="newage", min_velocity=60, max_velocity=80,
+                         track_role="main_melody", rhythm="standard", chord_progression=prog, num_generate=1,
+                         top_k=32, temperature=0.95))
+    assert enc == z["encoded_meta"].tolist()
+    comp = t.input_data.chord_token_components
+    assert comp["chord_token"] == z["chord_token"].tolist() and comp["chord_position"] == z["chord_position"].tolist()
