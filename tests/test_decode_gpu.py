@@ -183,3 +183,33 @@ def test_batched_kv_cache_decode_vs_reference_trace(golden_dir, tags):
             assert first is None or first > 12, (tag, first)
             if first is None and len(got) == len(ref):
                 assert gen.trace[b] == ref_trace
+
+
+def test_token_generation_pipeline_from_reference_arguments(golden_dir):
+    """generate.py's argument dictionary -> validated token sequences, 4 in parallel, with the fixture model whose
+    output bias makes valid ComMU grammar likely (g6).  Every returned sequence passes the reference's validators
+    and carries the forced chord progression."""
+    from commu_amd.midi_generator.generate_pipeline import TokenGenerationPipeline
+    from commu_amd.midi_generator.midi_inferrer import TOKEN_OFFSET
+    z = load(golden_dir, "g6_decode.npz")
+    model = _build(golden_dir, z, z["sample8_bias"])
+    prog = "-".join(["Am"] * 8 + ["G"] * 8 + ["F"] * 8 + ["E"] * 8)
+    args = dict(bpm=70, audio_key="aminor", time_signature="4/4", pitch_range="mid_high", num_measures=8.0,
+                inst="acoustic_piano", genre="newage", min_velocity=60, max_velocity=80, track_role="main_melody",
+                rhythm="standard", chord_progression=prog + "-" + prog, num_generate=4, top_k=32, temperature=0.95)
+    pipe = TokenGenerationPipeline(model, torch.device(DEV), generation_length=400)
+    seqs = pipe.execute(args, max_rounds=2)
+    assert pipe.preprocess_task.execute(args) == z["encoded_meta"].tolist()
+    assert pipe.attempts == len(seqs) + len(pipe.rejected) and pipe.attempts >= 4
+    forced_ok = seqs + [s for why, s in pipe.rejected if why == "no_note"]
+    assert forced_ok, [why for why, _ in pipe.rejected]          # the chord forcing itself must succeed
+    for s in forced_ok:
+        assert s[0] == 0 and s[1:12] == z["encoded_meta"].tolist() and s[-1] == TOKEN_OFFSET.EOS
+        assert s.count(TOKEN_OFFSET.BAR) == 8
+        chords = [t for t in s if TOKEN_OFFSET.CHORD_START <= t <= TOKEN_OFFSET.CHORD_END]
+        assert chords == z["sample8_chord_token"].tolist()
+    # the fixture model (random weights + a grammar bias) hardly ever emits a full note: those are the rejections
+    from commu_amd.midi_generator.midi_inferrer import InferenceTask
+    chk = InferenceTask(torch.device(DEV))
+    assert all(chk.validate_generated_sequence(s) for s in seqs)
+    assert not any(chk.validate_generated_sequence(s) for why, s in pipe.rejected if why == "no_note")
