@@ -37,12 +37,14 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._stream = None
+        # RCCL reduces to the mean directly; gloo (CPU tests, or CUDA tensors staged through the host) has no AVG
+        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
 
     def reduce_flat(self, flat_g: torch.Tensor, boundaries: Optional[List[int]] = None):
         if self.world == 1:
             return
         buckets = make_buckets(flat_g.numel(), boundaries or [], self.bucket_elems)
-        avg = flat_g.is_cuda            # RCCL reduces to the mean directly; gloo has no AVG
+        avg = self._avg
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
         handles = []
         # reverse order: the backward pass finishes the LAST parameters first
@@ -58,8 +60,7 @@ class GradReducer:
         self._handles, self._fired, self._pending = [], [], None
 
     def _fire(self, flat_g, a, b):
-        avg = flat_g.is_cuda
-        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
         self._fired.append((a, b))
 
@@ -90,7 +91,7 @@ class GradReducer:
             pos = max(pos, b)
         for h in self._handles:
             h.wait()
-        if not flat_g.is_cuda:
+        if not self._avg:
             flat_g.mul_(1.0 / self.world)
         self._handles = []
 
