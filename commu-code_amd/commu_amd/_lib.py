@@ -71,7 +71,7 @@ PROTOTYPES = {
     "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_sample_topk": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
     "commu_decode_kv_append": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "commu_decode_attn": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "commu_decode_attn": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
     "commu_hip_version": [],
 }

@@ -112,11 +112,9 @@ class DecodeState:
             w = m._weights(i)
             lay = m.layers[i]
             ops.gemm_nt(h, w["qkv"], out=self.qkv)
-            call("commu_decode_kv_append", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
-                 _p(self.klen), _p(active), B, self.Lmax, H, HD, _s())
             call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
                  _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
-                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, _s())
+                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, _s())      # (K/V append fused in)
             z1 = ops.gemm_nt(self.vec, w["o"], resid=h)
             a, _, _ = ops.layernorm_fwd(z1, lay.dec_attn.layer_norm.weight, lay.dec_attn.layer_norm.bias)
             hid = ops.gemm_nt(a, w["w1"], bias=w["b1"], relu=True)

@@ -49,10 +49,10 @@ __device__ __forceinline__ float oct_sum(float v) {
 // 64/LPR consecutive cache rows (LPR = DH/8 lanes per row), fully coalesced.
 template <int DH>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
-    const bf16* __restrict__ qkv, int ld_qkv, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+    const bf16* __restrict__ qkv, int ld_qkv, const bf16* kc, const bf16* vc,
     const bf16* __restrict__ rd, int ld_rd, const float* __restrict__ u, const float* __restrict__ vb,
     const int* __restrict__ klen, const unsigned char* __restrict__ active, bf16* __restrict__ out, int ld_o,
-    int H, int Lmax, float scale) {
+    int H, int Lmax, float scale, int append) {
     constexpr int LPR = DH / 8;            // lanes per row (8 for DH 64, 4 for DH 32)
     constexpr int RPW = 64 / LPR;          // rows per wave instruction
     __shared__ float sS[DEC_MAXK];
@@ -62,6 +62,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     if (active != nullptr && !active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane % LPR, rowl = lane / LPR;
+    if (append) {          // fused kv_append: this head's K and V of the new token go to cache row klen[b]
+        const int pos = klen[b];
+        if (pos < Lmax && tid < 2 * LPR) {
+            const int which = tid / LPR, c = tid % LPR;          // 0: K, 1: V
+            const bf16* src = qkv + (size_t)b * ld_qkv + (1 + which) * H * DH + h * DH + 8 * c;
+            bf16* dst = (bf16*)(which ? vc : kc) + (((size_t)b * H + h) * Lmax + pos) * DH + 8 * c;
+            st_bf16x8(dst, ld_bf16x8(src));
+        }
+        __syncthreads();          // workgroup-scope release/acquire: the row is read back below by other waves
+    }
     const int n = min(klen[b] + 1, Lmax);              // keys 0..klen[b] (the new token included)
     float qu[8], qv[8];
     {
@@ -161,21 +171,21 @@ extern "C" int commu_decode_kv_append(const void* qkv, int ld_qkv, void* kcache,
     return 0;
 }
 
-extern "C" int commu_decode_attn(const void* qkv, int ld_qkv, const void* kcache, const void* vcache,
+extern "C" int commu_decode_attn(const void* qkv, int ld_qkv, void* kcache, void* vcache,
                                  const void* rd, int ld_rd, const float* r_w_bias, const float* r_r_bias,
                                  const int* klen, const unsigned char* active, void* out, int ld_o, int B, int H,
-                                 int DH, int Lmax, float scale, hipStream_t stream) {
+                                 int DH, int Lmax, float scale, int append, hipStream_t stream) {
     if (B <= 0) return 0;
     if (Lmax > DEC_MAXK || (ld_qkv % 8) || (ld_rd % 8)) return -22;
     dim3 grid(B * H);
     if (DH == 64)
         COMMU_LAUNCH(decode_attn_kernel<64>, grid, dim3(256), 0, stream, (const bf16*)qkv, ld_qkv,
                      (const bf16*)kcache, (const bf16*)vcache, (const bf16*)rd, ld_rd, r_w_bias, r_r_bias, klen,
-                     active, (bf16*)out, ld_o, H, Lmax, scale);
+                     active, (bf16*)out, ld_o, H, Lmax, scale, append);
     else if (DH == 32)
         COMMU_LAUNCH(decode_attn_kernel<32>, grid, dim3(256), 0, stream, (const bf16*)qkv, ld_qkv,
                      (const bf16*)kcache, (const bf16*)vcache, (const bf16*)rd, ld_rd, r_w_bias, r_r_bias, klen,
-                     active, (bf16*)out, ld_o, H, Lmax, scale);
+                     active, (bf16*)out, ld_o, H, Lmax, scale, append);
     else
         return -22;
     COMMU_LAUNCH_CHECK();

@@ -260,11 +260,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 // 32 output columns, its 4 waves split K, and every wave issues ALL its fragment loads (weights and
 // activations, straight from global memory in MFMA operand layout) before the first MFMA: one round trip.
 // Partial sums meet in LDS; epilogue bias -> ReLU -> residual.
-template <int KSTEPS, bool OUT_F32>          // KSTEPS = K / 128: 32-wide MFMA steps per wave
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(
+template <int KSTEPS, bool OUT_F32, int NWV = 4>          // KSTEPS = K / (32 NWV): 32-wide MFMA steps per wave
+__global__ __launch_bounds__(64 * NWV) void gemm_nt_skinny_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
     int M, int N, const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr, int flags) {
-    __shared__ float red[4][32][64];
+    __shared__ float red[NWV][32][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 32;
     const int k0 = w * KSTEPS * 32 + 8 * g;
@@ -300,17 +300,20 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[w][(ni * 4 + mi) * 4 + e][lane] = acc[ni][mi][e];
     __syncthreads();
-    // wave w finishes blocks (ni = w >> 1, mi = 2 (w & 1) + {0, 1}); lane holds C[16 mi + r16][n0 + 16 ni + 4 g + e]
-    const int ni = w >> 1;
+    // the 8 (ni, mi) blocks are shared out over the waves; lane holds C[16 mi + r16][n0 + 16 ni + 4 g + e]
+    constexpr int BPW = 8 / NWV;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int mi = 2 * (w & 1) + q;
+    for (int q = 0; q < BPW; ++q) {
+        const int blk = w * BPW + q, ni = blk >> 2, mi = blk & 3;
         const int m = 16 * mi + r16, n = n0 + 16 * ni + 4 * g;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = (ni * 4 + mi) * 4 + e;
-            v[e] = red[0][idx][lane] + red[1][idx][lane] + red[2][idx][lane] + red[3][idx][lane];
+            float acc1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NWV; ++ww) acc1 += red[ww][idx][lane];
+            v[e] = acc1;
         }
         if (m >= M || n >= N) continue;
 #pragma unroll
@@ -541,24 +544,31 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
     if (M <= 64 && batch == 1 && bs.tri_B == 0 && (K % 128) == 0 && K <= 1024 && N >= 32 &&
         !(flags & (COMMU_EPI_DROPOUT | COMMU_EPI_RELUMASK)) && !getenv("COMMU_GEMM_NOSKINNY")) {
         dim3 grid((N + 31) / 32);
-#define SK_LAUNCH(KS)                                                                                                \
+#define SK_LAUNCH(KS, NWV)                                                                                           \
     {                                                                                                                \
         if (flags & COMMU_EPI_OUT_F32)                                                                               \
-            COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, true>), grid, dim3(256), 0, stream, (const bf16*)A, lda,         \
-                         (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);                   \
+            COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, true, NWV>), grid, dim3(64 * NWV), 0, stream, (const bf16*)A,    \
+                         lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);              \
         else                                                                                                         \
-            COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, false>), grid, dim3(256), 0, stream, (const bf16*)A, lda,        \
-                         (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);                   \
+            COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, false, NWV>), grid, dim3(64 * NWV), 0, stream, (const bf16*)A,   \
+                         lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);              \
     }
-        switch (K / 128) {
-            case 1: SK_LAUNCH(1) break;
-            case 2: SK_LAUNCH(2) break;
-            case 3: SK_LAUNCH(3) break;
-            case 4: SK_LAUNCH(4) break;
-            case 5: SK_LAUNCH(5) break;
-            case 6: SK_LAUNCH(6) break;
-            case 7: SK_LAUNCH(7) break;
-            default: SK_LAUNCH(8) break;
+        if (K % 256 == 0 && K >= 768) {          // long contraction: 8 waves split K
+            switch (K / 256) {
+                case 3: SK_LAUNCH(3, 8) break;
+                default: SK_LAUNCH(4, 8) break;
+            }
+        } else {
+            switch (K / 128) {
+                case 1: SK_LAUNCH(1, 4) break;
+                case 2: SK_LAUNCH(2, 4) break;
+                case 3: SK_LAUNCH(3, 4) break;
+                case 4: SK_LAUNCH(4, 4) break;
+                case 5: SK_LAUNCH(5, 4) break;
+                case 6: SK_LAUNCH(6, 4) break;
+                case 7: SK_LAUNCH(7, 4) break;
+                default: SK_LAUNCH(8, 4) break;
+            }
         }
 #undef SK_LAUNCH
         COMMU_LAUNCH_CHECK();

@@ -13,6 +13,28 @@ namespace {
 
 constexpr int PER_LANE = 12;      // 64 * 12 = 768 >= 729: lane l owns ids [12 l, 12 l + 12)
 
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+// arg-max over the wave (ties: lowest id), result in every lane.  Four DPP steps inside the 16-lane rows (VALU
+// speed), then two ds_bpermute exchanges across rows -- the all-shuffle version spent 12 LDS round trips per call,
+// 32 calls per draw.
+__device__ __forceinline__ void wave_argmax(float& best, int& bi) {
+#define COMMU_ARGMAX_STEP(OB, OI)                                                        \
+    {                                                                                    \
+        const float ob = (OB);                                                           \
+        const int oi = (OI);                                                             \
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }                \
+    }
+    COMMU_ARGMAX_STEP(dpp_f<0xB1>(best), dpp_i<0xB1>(bi))
+    COMMU_ARGMAX_STEP(dpp_f<0x4E>(best), dpp_i<0x4E>(bi))
+    COMMU_ARGMAX_STEP(dpp_f<0x141>(best), dpp_i<0x141>(bi))
+    COMMU_ARGMAX_STEP(dpp_f<0x140>(best), dpp_i<0x140>(bi))
+    COMMU_ARGMAX_STEP(__shfl_xor(best, 16, 64), __shfl_xor(bi, 16, 64))
+    COMMU_ARGMAX_STEP(__shfl_xor(best, 32, 64), __shfl_xor(bi, 32, 64))
+#undef COMMU_ARGMAX_STEP
+}
+
 __global__ __launch_bounds__(64) void sample_topk_kernel(float* __restrict__ logits, int ld, int V,
                                                          const unsigned char* __restrict__ wrong, int ldw,
                                                          const float* __restrict__ uni,
@@ -78,12 +100,7 @@ __global__ __launch_bounds__(64) void sample_topk_kernel(float* __restrict__ log
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e)
             if (q[e] > best) { best = q[e]; bi = base + e; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
+        wave_argmax(best, bi);
         const int off = bi - base;
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e)

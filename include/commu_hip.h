@@ -200,10 +200,12 @@ int commu_sample_topk(float* logits, int ld, int nseq, int V, const unsigned cha
 int commu_decode_kv_append(const void* qkv, int ld_qkv, void* kcache, void* vcache, const int* klen,
                            const unsigned char* active, int B, int Lmax, int H, int HD, hipStream_t stream);
 /* out[b, h*DH:(h+1)*DH] = softmax_j(((q+u).k_j + (q+v).Rd[klen[b]-j]) * scale) . v_j   (rd: [>= Lmax][ld_rd]) */
-int commu_decode_attn(const void* qkv, int ld_qkv, const void* kcache, const void* vcache, const void* rd,
+/* append != 0: the kernel first writes the new token's K and V (from qkv) to cache row klen[b] itself
+ * (commu_decode_kv_append fused in; the caches are then written through kcache / vcache) */
+int commu_decode_attn(const void* qkv, int ld_qkv, void* kcache, void* vcache, const void* rd,
                       int ld_rd, const float* r_w_bias, const float* r_r_bias, const int* klen,
                       const unsigned char* active, void* out, int ld_o, int B, int H, int DH, int Lmax,
-                      float scale, hipStream_t stream);
+                      float scale, int append, hipStream_t stream);
 /* klen[b] += advance[b]  (a step whose memory the reference discards does not advance: quirk Q3) */
 int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lmax, hipStream_t stream);
 
