@@ -50,6 +50,7 @@ PROTOTYPES = {
     "commu_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_colsum_bf16": [c_p, c_i, c_i, c_i, c_p, c_p],
     "commu_colsum_f32": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "commu_layernorm_bwd_reduce": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "commu_ce_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_ce_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "commu_masked_mean": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],

@@ -578,9 +578,8 @@ class MemTransformerLM(nn.Module):
                                           dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3))
             if dz2m is None:
                 dz2m = dz2
-            ops.colsum(part[:, 0], gv(pre + "pos_ff.layer_norm.weight", (Dt,)))
-            ops.colsum(part[:, 1], gv(pre + "pos_ff.layer_norm.bias", (Dt,)))
-            ops.colsum(part[:, 2], gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)))
+            ops.layernorm_bwd_reduce(part, gv(pre + "pos_ff.layer_norm.weight", (Dt,)),
+                                     gv(pre + "pos_ff.layer_norm.bias", (Dt,)), gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)))
             wgrad(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
             dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
             wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
@@ -591,8 +590,8 @@ class MemTransformerLM(nn.Module):
                                           dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1))
             if dz1m is None:
                 dz1m = dz1
-            ops.colsum(part[:, 0], gv(pre + "dec_attn.layer_norm.weight", (Dt,)))
-            ops.colsum(part[:, 1], gv(pre + "dec_attn.layer_norm.bias", (Dt,)))
+            ops.layernorm_bwd_reduce(part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)),
+                                     gv(pre + "dec_attn.layer_norm.bias", (Dt,)))
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]

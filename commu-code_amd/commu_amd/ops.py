@@ -211,6 +211,13 @@ def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, 
     return dz, part[:nblk]
 
 
+def layernorm_bwd_reduce(part, dgamma, dbeta, dbias=None):
+    """One launch for the three partial-sum planes of layernorm_bwd: accumulates into the gradients."""
+    nblk, _, D = part.shape
+    assert part.is_contiguous() and part.dtype == F32
+    call("commu_layernorm_bwd_reduce", _p(part), nblk, D, _p(dgamma), _p(dbeta), _p(dbias), _s())
+
+
 def colsum(X, out):
     """out[c] += sum_r X[r, c]  (X bf16 or fp32)."""
     rows, cols = X.shape

@@ -309,6 +309,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
     }
 }
 
+// the three partial-sum planes of layernorm_bwd ([nblk][3][D]) reduced by ONE launch: plane z -> out{z}
+__global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ part, int rows, int D,
+                                                      float* __restrict__ o0, float* __restrict__ o1,
+                                                      float* __restrict__ o2, int rows_per_block) {
+    __shared__ float red[4][256];
+    const int z = blockIdx.z;
+    float* out = z == 0 ? o0 : (z == 1 ? o1 : o2);
+    if (out == nullptr) return;
+    const float* X = part + (size_t)z * D;
+    const int ldx = 3 * D;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 256 + lane * 4;
+    const int rbeg = blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < D) {
+        for (int r = rbeg + w; r < rend; r += 4) {
+            const float* p = X + (size_t)r * ldx + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < D) a[e] += p[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < D) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // bf16 fast path: 16-byte loads (8 columns per lane, 512 per workgroup), 4 rows in flight per wave
 __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16* __restrict__ X, int ldx, int rows, int cols,
                                                             float* __restrict__ out, int rows_per_block) {
@@ -612,6 +641,18 @@ extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, flo
     const int rpb = (rows + ny - 1) / ny;
     COMMU_LAUNCH(colsum_kernel<bf16>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream,
                        (const bf16*)X, ldx, rows, cols, out, rpb);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_layernorm_bwd_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta,
+                                          float* dbias, hipStream_t stream) {
+    if (nblk <= 0 || D <= 0) return 0;
+    int ny = (nblk + 63) / 64;
+    if (ny > 64) ny = 64;
+    const int rpb = (nblk + ny - 1) / ny;
+    COMMU_LAUNCH(colsum3_kernel, dim3((D + 255) / 256, ny, 3), dim3(256), 0, stream, part, nblk, D, dgamma, dbeta, dbias,
+                 rpb);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -95,6 +95,9 @@ int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const 
                         const float* rstd, const float* gamma, void* dz, int lddz, float* part, int rows,
                         int D, void* dz_masked, int lddzm, unsigned drop_seed, float drop_p,
                         hipStream_t stream);
+/* dgamma += sum_blocks part[:,0,:], dbeta += part[:,1,:], dbias += part[:,2,:] (each destination optional) */
+int commu_layernorm_bwd_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta, float* dbias,
+                               hipStream_t stream);
 /* out[c] += sum_r X[r,c]   (bias gradients) */
 int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
 int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
