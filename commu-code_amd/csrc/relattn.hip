@@ -392,292 +392,6 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
 }
 
 // =============================================================================================
-// forward, LDS-DMA variant: 128 query rows per workgroup (8 waves x 16 rows), K / V / band tiles go HBM/L2 -> LDS
-// with `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write, out-of-range rows still read as zero),
-// single-buffered: K(t+1) and the band chunk are requested as soon as every wave has issued its QK / QR reads of
-// tile t, V(t+1) after the P.V reads; two barriers per tile as before.  Every LDS access inside the loop is inline
-// asm with hand-placed waits: the compiler would otherwise put a vmcnt(0) in front of each LDS access that follows a
-// DMA and serialise request -> wait -> use.  128 VGPRs -> 4 waves per SIMD, half the staged bytes per flop.
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(LDS_AS const void*)p; }
-// (base address in a VGPR + compile-time byte offset: per-fragment address registers would be hoisted out of the
-//  tile loop and spilled)
-#define COMMU_LDS_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define COMMU_LDS_RD64TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define COMMU_LDS_WR64(addr, off, val) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(off) : "memory")
-#define COMMU_LDS_WAIT8(x) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x))
-
-template <bool DROP>
-__global__ __launch_bounds__(512, 4) void relattn_fwd_dma_kernel(const AttnArgs a) {
-    constexpr int DH = 64, KS = 2, DB = 4, NW = 8, QROWS = 128, NCH = 4;      // band ring: 3 chunks in use + 1 being filled
-    // one LDS block with compile-time offsets, so that a single lane address register serves K and the band
-    // (K and V double-buffered: all of tile t+1 is requested at the top of tile t -- a whole tile of lead, ONE barrier
-    //  per tile; 80 KiB per workgroup = two workgroups per CU exactly)
-    constexpr int OFF_K = 0, OFF_V = 2 * 64 * DH, OFF_R = 4 * 64 * DH, OFF_P = (4 + NCH) * 64 * DH;      // in elements
-    __shared__ __attribute__((aligned(16))) bf16 smem[OFF_P + NW * 64 * PT];
-    bf16* const sK = smem + OFF_K;
-    bf16* const sV = smem + OFF_V;
-    bf16* const sR = smem + OFF_R;
-    bf16* const sP = smem + OFF_P;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    const int QT = (a.T + QROWS - 1) / QROWS;
-    int qt, h, b;
-    tile_coords(QT, a.H, a.B, qt, h, b);
-    qt = QT - 1 - qt;
-    const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
-    const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
-    const unsigned rsb = (unsigned)B * a.ld_qkv * 2u, rdb = (unsigned)a.ld_rd * 2u;
-    const float c2 = a.scale * LOG2E;
-
-    bf16x8 qu[KS], qv[KS];
-    {
-        const int irow = i0 + 16 * w + r16;
-        const int iq = min(irow, T - 1);
-        const bf16* qp = a.q + ((size_t)iq * B + b) * a.ld_qkv + h * DH;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 raw = ld_bf16x8(qp + 32 * ks + 8 * g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int f = h * DH + 32 * ks + 8 * g + e;
-                const float x = bf2f(raw[e]);
-                qu[ks][e] = f2bf((x + a.u[f]) * c2);
-                qv[ks][e] = f2bf((x + a.vb[f]) * c2);
-            }
-            if (a.qu2 != nullptr && irow < T) {
-                const size_t off = ((size_t)irow * B + b) * (a.H * DH) + h * DH + 32 * ks + 8 * g;
-                st_bf16x8(a.qu2 + off, qu[ks]);
-                st_bf16x8(a.qv2 + off, qv[ks]);
-            }
-        }
-    }
-    int srcaddr[4];
-    bool lower[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
-        lower[reg] = r16 < 4 * g + reg;
-    }
-    f32x4 o[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrow[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    float lpart[4] = {0.f, 0.f, 0.f, 0.f};
-
-    int jt_lo, jt_hi;
-    kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
-
-    const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
-    const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
-    const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
-    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
-    // DMA piece of wave w = rows 8w..8w+7 of a 64-row tile (1 KiB, lane-linear in LDS): lane holds row 8w + lane/8,
-    // physical 16-byte chunk lane%8, i.e. logical chunk (lane%8) ^ (row & 7) of the swizzled image
-    const int drow = 8 * w + (lane >> 3), dch = (lane & 7) ^ (drow & 7);
-    const unsigned voffKV = (unsigned)drow * rsb + (unsigned)dch * 16u, voffR = (unsigned)drow * rdb + (unsigned)dch * 16u;
-    auto dmaK = [&](int jt, int buf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdK, (LDS_AS void*)(sK + buf * 64 * DH + w * 512), 16,
-                                                 (int)(voffKV + (unsigned)(jt * 64) * rsb), 0, 0, 0);
-    };
-    auto dmaV = [&](int jt, int buf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdV, (LDS_AS void*)(sV + buf * 64 * DH + w * 512), 16,
-                                                 (int)(voffKV + (unsigned)(jt * 64) * rsb), 0, 0, 0);
-    };
-    auto dmaR = [&](int dlo, int slot) {          // 64 band rows starting at distance dlo (negative wraps: zeros)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdR, (LDS_AS void*)(sR + slot * 64 * DH + w * 512), 16,
-                                                 (int)(voffR + (unsigned)dlo * rdb), 0, 0, 0);
-    };
-    {
-        const int dlo0 = i0 + M - jt_lo * 64 - 63;
-        dmaR(dlo0 + 64, 1);
-        dmaR(dlo0 + 128, 2);
-        dmaR(dlo0, 0);
-        dmaK(jt_lo, 0);
-        dmaV(jt_lo, 0);
-    }
-
-    const unsigned swz16 = (unsigned)(r16 & 7);
-    // lane-constant LDS byte addresses; everything else is a compile-time offset (or one XOR, see the V reads)
-    // fragment (row r16 + 16 n, k-step 0) of the K tile; k-step 1 is the same address XOR 64 (chunk index ^ 4), the
-    // band tile sits OFF_R elements further
-    const unsigned aK0 = lds_addr(sK) + (unsigned)(r16 * DH + ((g ^ swz16) << 3)) * 2u;
-    const unsigned aPw = lds_addr(sP + w * 64 * PT) + (unsigned)(r16 * PT + 4 * g) * 2u;              // + c * 16 * PT * 2
-    const unsigned aPr = lds_addr(sP + w * 64 * PT) + (unsigned)((8 * g + (r16 >> 2)) * PT + 4 * (r16 & 3)) * 2u;
-    // V transpose reads: row = 32 ks + 8 g + 4 hh + (r16 >> 2), column = 16 d + 4 (r16 & 3); the swizzled chunk is
-    // (2 d) ^ (const of the lane), so the address of block d is the address of block 0 XOR (d << 5)
-    unsigned aVh[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int row = 8 * g + 4 * hh + (r16 >> 2), col = 4 * (r16 & 3);
-        aVh[hh] = lds_addr(sV) + (unsigned)(row * DH + (((col >> 3) ^ (row & 7)) << 3) + (col & 7)) * 2u;
-    }
-    const int iw_lo = i0 + 16 * w, iw_hi = iw_lo + 15;
-    for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
-        const int j0 = jt * 64;
-        // ---- tile t has landed (requested a whole tile ago) and everyone is done with tile t-1: request tile t+1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (jt < jt_hi) {
-            dmaK(jt + 1, (t + 1) & 1);
-            dmaV(jt + 1, (t + 1) & 1);
-            dmaR(i0 + M - (j0 + 64) - 63, ((NCH - 1) * (t + 1)) % NCH);
-        }
-        const unsigned kvb = (unsigned)((t & 1) * 64 * DH * 2);          // byte offset of this tile's K / V buffer
-        // ---- band product, fragments in batches of four reads (bounded register footprint: 128 VGPRs in all)
-        f32x4 qr[5];
-#pragma unroll
-        for (int blk = 0; blk < 5; ++blk) qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b0 = 0; b0 < 5; b0 += 2) {
-            bf16x8 rf[2][KS];
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                if (b0 + bb < 5) {
-                    const unsigned roff = (unsigned)ring_row<NCH, NCH - 1>(16 * w + 16 * (b0 + bb), t) * (DH * 2);   // wave-uniform
-                    const unsigned ra0 = aK0 + roff, ra1 = ra0 ^ 64u;
-                    COMMU_LDS_RD128(rf[bb][0], ra0, (OFF_R - OFF_K) * 2);
-                    COMMU_LDS_RD128(rf[bb][1], ra1, (OFF_R - OFF_K) * 2);
-                }
-            }
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-                if (b0 + bb < 5) {
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) COMMU_LDS_WAIT8(rf[bb][ks]);
-                }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
-                    if (b0 + bb < 5) qr[b0 + bb] = mfma16(qv[ks], rf[bb][ks], qr[b0 + bb]);
-        }
-        f32x4 s[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
-                        t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
-            s[0][reg] = bperm(srcaddr[reg], t0);
-            s[1][reg] = bperm(srcaddr[reg], t1);
-            s[2][reg] = bperm(srcaddr[reg], t2);
-            s[3][reg] = bperm(srcaddr[reg], t3);
-        }
-        const unsigned aKt = aK0 + kvb, aK1 = aKt ^ 64u;
-#pragma unroll
-        for (int c0 = 0; c0 < 4; c0 += 2) {
-            bf16x8 kf[2][KS];
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                COMMU_LDS_RD128(kf[cc][0], aKt, (c0 + cc) * 16 * DH * 2);
-                COMMU_LDS_RD128(kf[cc][1], aK1, (c0 + cc) * 16 * DH * 2);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) COMMU_LDS_WAIT8(kf[cc][ks]);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) s[c0 + cc] = mfma16(qu[ks], kf[cc][ks], s[c0 + cc]);
-        }
-        const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
-                               (rst && j0 < M) || (iw_hi >= T);
-        if (need_mask) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int i = iw_lo + 4 * g + reg;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst)) s[c][reg] = -INFINITY;
-            }
-        }
-        float mnew[4];
-        bool grew = false;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            float mx = fmaxf(fmaxf(s[0][reg], s[1][reg]), fmaxf(s[2][reg], s[3][reg]));
-            mx = row16_max(mx);
-            mnew[reg] = fmaxf(mrow[reg], mx);
-            grew |= mnew[reg] > mrow[reg];
-        }
-        if (__any(grew)) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float alpha = __builtin_amdgcn_exp2f(mrow[reg] - mnew[reg]);
-                mrow[reg] = mnew[reg];
-                lpart[reg] *= alpha;
-#pragma unroll
-                for (int d = 0; d < DB; ++d) o[d][reg] *= alpha;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x4 pb;
-            unsigned hw[2] = {0u, 0u};
-            if (DROP) {
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp)
-                    hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
-                lpart[reg] += p;
-                if (DROP) p = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? p * a.drop_scale : 0.f;
-                pb[reg] = f2bf(p);
-            }
-            COMMU_LDS_WR64(aPw, c * 16 * PT * 2, pb);       // P^T[kv][row]: rows 4g..4g+3
-        }
-        // ---- P.V: P^T and V fragments by transpose reads (same wave wrote P: LDS keeps a wave's accesses in order)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x4 ph[2], vh[DB][2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                COMMU_LDS_RD64TR(ph[hh], aPr, (32 * ks + 4 * hh) * PT * 2);
-#pragma unroll
-                for (int d = 0; d < DB; ++d) {
-                    const unsigned va = (aVh[hh] ^ (unsigned)(d << 5)) + kvb;
-                    COMMU_LDS_RD64TR(vh[d][hh], va, 32 * ks * DH * 2);
-                }
-            }
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ph[hh]));
-#pragma unroll
-                for (int d = 0; d < DB; ++d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vh[d][hh]));
-            }
-            bf16x8 pf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { pf[e] = ph[0][e]; pf[4 + e] = ph[1][e]; }
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                bf16x8 vf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = vh[d][0][e]; vf[4 + e] = vh[d][1][e]; }
-                o[d] = mfma16(pf, vf, o[d]);
-            }
-        }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const float l = row16_sum(lpart[reg]);
-        const float inv = 1.f / l;
-        const int i = i0 + 16 * w + 4 * g + reg;
-        if (i < T) {
-            bf16* op = a.out + ((size_t)i * B + b) * a.ld_o + h * DH;
-#pragma unroll
-            for (int d = 0; d < DB; ++d) op[16 * d + r16] = f2bf(o[d][reg] * inv);
-            if (r16 == 0) a.lse[((size_t)b * a.H + h) * T + i] = (mrow[reg] + __log2f(l)) * LN2;
-        }
-    }
-}
-#undef COMMU_LDS_WAIT8
-#undef COMMU_LDS_RD128
-#undef COMMU_LDS_RD64TR
-#undef COMMU_LDS_WR64
-
-// =============================================================================================
 // backward, q-stationary: dq_AC = dS.K (+ its column sums for d r_w_bias) and dS written by
 // DISTANCE (dSk[i][d = i+M-j]) for the two GEMMs  dq_BD = dSk.Rd  and  dRd = dSk^T.(q+v).
 template <int DH, int NW, bool DROP>
@@ -1160,15 +874,8 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
     // (the kernels are parametrised by waves per workgroup; 8-wave / 128-row tiles measured slower than 4-wave
     // tiles at every shape of this model, so only NW = 4 is instantiated)
-    const bool drop = a.drop_thr != 0u;
-    if (d->DH == 64 && d->T >= 128 && getenv("COMMU_ATTN_DMA")) {
-        dim3 gridw(((d->T + 127) / 128) * d->H * d->B);
-        if (drop) COMMU_LAUNCH((relattn_fwd_dma_kernel<true>), gridw, dim3(512), 0, stream, a);
-        else COMMU_LAUNCH((relattn_fwd_dma_kernel<false>), gridw, dim3(512), 0, stream, a);
-        COMMU_LAUNCH_CHECK();
-        return 0;
-    }
     dim3 grid(((d->T + 63) / 64) * d->H * d->B);
+    const bool drop = a.drop_thr != 0u;
 #define ATTN_FWD(DHV)                                                                              \
     {                                                                                              \
         if (drop) COMMU_LAUNCH((relattn_fwd_kernel<DHV, 4, true>), grid, dim3(256), 0, stream, a); \
