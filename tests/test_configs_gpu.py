@@ -166,3 +166,25 @@ def test_evaluate_same_length_memory_window_vs_oracle():
     assert tok == ref_tok
     assert abs(nll / tok - ref_nll / ref_tok) < 6e-3, (nll / tok, ref_nll / ref_tok)
     assert model.training and model.mem_len == cfg.TRAIN.mem_length and model.same_length == cfg.MODEL.same_length
+
+
+def test_training_learns_a_deterministic_rule():
+    """End-to-end sanity of forward + backward + clip + Adam + LR schedule: x[t+1] = x[t] + 3 (mod 700) is learned
+    to near-zero loss in 150 optimiser steps (a wrong gradient anywhere stalls near ln 729 = 6.59)."""
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab
+    from commu_amd.train import Trainer, build_model
+    dev = torch.device(DEV)
+    T, B = 64, 16
+    cfg = get_cfg(num_layers=2, num_heads=4, units=128, inner_size=256, tgt_length=T, mem_length=T, batch_size=B,
+                  batch_chunk=1, dropout=0.0, attention_dropout=0.0)
+    tr = Trainer(build_model(cfg, BaseVocab(), dev, seed=1), cfg)
+    g = torch.Generator().manual_seed(0)
+    first = last = None
+    for s in range(150):
+        start = torch.randint(2, 700, (1, B), generator=g)
+        seq = (start + 3 * torch.arange(T + 1)[:, None]) % 700 + 2
+        loss = tr.step(seq[:-1].to(dev), seq[1:].to(dev), torch.ones(B, dtype=torch.bool, device=dev), T * B)
+        last = float(loss.detach())
+        first = last if first is None else first
+    assert first > 6.0 and last < 0.1, (first, last)
