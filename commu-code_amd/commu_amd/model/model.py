@@ -404,6 +404,12 @@ class MemTransformerLM(nn.Module):
         K = T + M
         TB = T * B
         tokens = data.contiguous().view(-1)
+        if getattr(self, "check_inputs", False):
+            # the reference raises IndexError on ids outside the vocabulary (nn.Embedding / gather); the kernels do
+            # not bounds-check, so debugging runs can turn this host-synchronising check on
+            lo, hi = int(tokens.min()), int(tokens.max())
+            if lo < 0 or hi >= V or (target is not None and (int(target.min()) < 0 or int(target.max()) >= V)):
+                raise IndexError(f"token id out of range [0, {V}): min {lo}, max {hi}")
         rst = None
         if reset is not None and M > 0:
             rst = reset.to(device=dev, dtype=torch.uint8).contiguous()

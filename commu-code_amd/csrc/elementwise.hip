@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) { atomicAdd(sum, s); if (c) atomicAdd(cnt, c); }
 }
 __global__ void masked_mean_final_kernel(const float* sum, const int* cnt, float scale, float* out) {
-    out[0] = scale * sum[0] / (float)max(cnt[0], 1);
+    // no non-pad target: the reference's `loss[target != pad].mean()` of an empty selection is NaN (and its gradient
+    // is all zeros, which loss_grad produces anyway)
+    out[0] = cnt[0] > 0 ? scale * sum[0] / (float)cnt[0] : __builtin_nanf("");
 }
 
 __global__ void copy_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, size_t n8) {

@@ -107,7 +107,8 @@ int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll
                  int V, hipStream_t stream);
 int commu_ce_bwd(const float* logits, int ldl, const int64_t* target, const float* lse, const float* g,
                  void* dlogits_bf16, int ldd, int rows, int V, hipStream_t stream);
-/* out[0] = scale * mean(nll[target != pad])   (train.py:148-149); keeps the count in cnt_ws */
+/* out[0] = scale * mean(nll[target != pad])   (train.py:148-149); keeps the count in cnt_ws; NaN when every
+ * target is the pad id (mean of an empty selection, as in the reference) */
 int commu_masked_mean(const float* nll, const int64_t* target, int n, int pad, float scale, float* sum_ws,
                       int* cnt_ws, float* out, hipStream_t stream);
 int commu_loss_grad(const int64_t* target, int n, int pad, const int* cnt_ws, float scale, float* g,

@@ -270,3 +270,24 @@ def test_checkpoint_roundtrip_resumes_identically(tmp_path):
     st = adam.state[ref_params[3]]
     assert float(st["step"]) == 3.0 and st["exp_avg"].shape == ref_params[3].shape
     assert float(st["exp_avg_sq"].abs().sum()) > 0
+
+
+def test_all_pad_targets_and_input_check(golden_dir):
+    """Edge cases of the loss reduction: a micro-batch whose targets are all pads gives NaN like the reference's
+    `loss[target != pad].mean()` of an empty selection, never a crash; `check_inputs` reports ids outside the
+    vocabulary as the reference's embedding would (IndexError)."""
+    from commu_amd.functional import masked_mean
+    z = load(golden_dir, "g1_train_nomem.npz")
+    model, cfg = build_from_fixture(z)
+    model.eval()
+    data = torch.from_numpy(z["data0"]).to(DEV)
+    target = torch.zeros_like(data)
+    loss, _ = model(data, target, torch.zeros(data.shape[1], dtype=torch.bool, device=DEV), None)
+    assert torch.isfinite(loss).all()                       # per-token NLL is still defined
+    m = masked_mean(loss, target, 0, 1.0)
+    assert torch.isnan(m) and torch.isnan(loss[target != 0].float().mean())
+    model.check_inputs = True
+    bad = data.clone()
+    bad[0, 0] = 729
+    with pytest.raises(IndexError):
+        model(bad, target, torch.zeros(data.shape[1], dtype=torch.bool, device=DEV), None)
