@@ -550,6 +550,19 @@ class MemTransformerLM(nn.Module):
             if side is not None:
                 main.wait_stream(side)
 
+        def defer(fn):          # fn's kernels go to the side stream, ordered after what main has enqueued so far
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+        # dS-by-distance scratch: two buffers alternate between layers, so that the deferred dRd GEMM of layer i may
+        # still read its buffer while layer i-1's attention backward fills the other one
+        scr = fl.setdefault("attn_scratch", [{}, {}])
+        scr_free = [None, None]          # event: the side stream is done with that buffer
+
         T, M, B = sv.T, sv.M, sv.B
         # Dt/DIt/DHt: the model's (state_dict) dimensions; D/DI/DH: kernel-side, possibly zero-padded
         Dt, DIt, DHt = self.d_model, self.d_inner, self.d_head
@@ -605,12 +618,21 @@ class MemTransformerLM(nn.Module):
             if M > 0:
                 dqkv[:M * B, :HD].zero_()
             drd = torch.empty(K, HD, device=dev, dtype=F32)
+            if scr_free[i & 1] is not None:
+                main.wait_event(scr_free[i & 1])          # (layer i+2's dRd GEMM has released this scratch buffer)
             ops.relattn_bwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], sv.rd[i], u_k,
                             vb_k, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
-                            scratch=fl.setdefault("attn_scratch", {}))
-            wgrad(ops.cast_bf16(drd), sv.pd, gv(pre + "dec_attn.r_net.weight", (HDt, Dt)), crop=spec("r"))
+                            scratch=scr[i & 1], defer=defer if side is not None else None)
+            gWr = gv(pre + "dec_attn.r_net.weight", (HDt, Dt))
+            if side is None:
+                self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"))
+            else:
+                keep.append(drd)
+                defer(lambda drd=drd, gWr=gWr: self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r")))
+                scr_free[i & 1] = torch.cuda.Event()
+                scr_free[i & 1].record(side)
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
             wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))
             if M > 0:

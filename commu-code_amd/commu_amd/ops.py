@@ -342,7 +342,7 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
-                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None):
+                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None, defer=None):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
     drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
     dev = q.device
@@ -395,11 +395,17 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     TB = T * B
     call("commu_gemm_nt_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(rdt), ld_dsk, DH * ld_dsk, _p(dq), dq.stride(0),
          DH, TB, DH, ld_dsk, _p(dq_ac), HD, DH, EPI_RESID, H, tri_B, tri_M, _s())
-    ns = tn_slices(TB, ld_dsk, DH * H)
-    slabs = torch.empty(H * ns * ld_dsk * DH, device=dev, dtype=F32)
-    call("commu_gemm_tn_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(qv2), HD, DH, _p(slabs), DH, ld_dsk * DH, TB,
-         ld_dsk, DH, ns, H, tri_B, tri_M, _s())
-    call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, ns, ld_dsk * DH, H, 0, 1.0 / c2, _s())
+    def drd_part():
+        # dRd only feeds r_net's weight gradient: `defer` (optional) runs it off the critical path (side stream)
+        ns = tn_slices(TB, ld_dsk, DH * H)
+        slabs = torch.empty(H * ns * ld_dsk * DH, device=dev, dtype=F32)
+        call("commu_gemm_tn_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(qv2), HD, DH, _p(slabs), DH, ld_dsk * DH, TB,
+             ld_dsk, DH, ns, H, tri_B, tri_M, _s())
+        call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, ns, ld_dsk * DH, H, 0, 1.0 / c2, _s())
+    if defer is None:
+        drd_part()
+    else:
+        defer(drd_part)
     # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)
     ca = torch.zeros(HD, device=dev, dtype=F32)
     colsum(du_part, ca)
