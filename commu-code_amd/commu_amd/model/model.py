@@ -573,7 +573,8 @@ class MemTransformerLM(nn.Module):
         sh = fl["shadow"]
         g = dloss.reshape(-1).to(F32)
         dlogits = ops.ce_bwd(sv.logits, sv.target, sv.ce_lse, g, V)             # [TB, 768] bf16, pad cols 0
-        ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)))
+        keep.append(dlogits)
+        defer(lambda: ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,))))
         gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
         wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))
         p, patt = sv.p, sv.patt
@@ -597,20 +598,23 @@ class MemTransformerLM(nn.Module):
                                           dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3))
             if dz2m is None:
                 dz2m = dz2
-            ops.layernorm_bwd_reduce(part, gv(pre + "pos_ff.layer_norm.weight", (Dt,)),
-                                     gv(pre + "pos_ff.layer_norm.bias", (Dt,)), gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)))
+            keep.append(part)
+            defer(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
+                part, gv(pre + "pos_ff.layer_norm.weight", (Dt,)), gv(pre + "pos_ff.layer_norm.bias", (Dt,)),
+                gv(pre + "pos_ff.CoreNet.3.bias", (Dt,))))
             wgrad(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
             dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
             wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
-            ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)))
+            defer(lambda dhid=dhid, pre=pre: ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,))))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
                                           dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1))
             if dz1m is None:
                 dz1m = dz1
-            ops.layernorm_bwd_reduce(part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)),
-                                     gv(pre + "dec_attn.layer_norm.bias", (Dt,)))
+            keep.append(part)
+            defer(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
+                part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)), gv(pre + "dec_attn.layer_norm.bias", (Dt,))))
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]

@@ -406,13 +406,20 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         drd_part()
     else:
         defer(drd_part)
-    # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)
-    ca = torch.zeros(HD, device=dev, dtype=F32)
-    colsum(du_part, ca)
-    ct = torch.zeros(HD, device=dev, dtype=F32)
-    colsum(dq, ct)
-    du.add_(ca)
-    dvb.add_(ct - ca)
+    def bias_part():
+        # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)   (gradients only: deferrable)
+        if defer is not None:          # local scratch outlives this function on the deferring stream
+            du_part.record_stream(torch.cuda.current_stream())
+        ca = torch.zeros(HD, device=dev, dtype=F32)
+        colsum(du_part, ca)
+        ct = torch.zeros(HD, device=dev, dtype=F32)
+        colsum(dq, ct)
+        du.add_(ca)
+        dvb.add_(ct - ca)
+    if defer is None:
+        bias_part()
+    else:
+        defer(bias_part)
     return delta
 
 
