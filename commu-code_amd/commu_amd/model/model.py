@@ -294,13 +294,30 @@ class MemTransformerLM(nn.Module):
             if key not in sh:
                 sh[key] = torch.zeros(shape[1], cols, device=dev, dtype=BF16)
             ops.transpose_to_bf16(w, sh[key][:, :shape[0]])
-        tr("Et", "word_emb.emb_layers.0.weight", (V, D), VPAD)
-        for i in range(self.n_layer):
-            pre = f"layers.{i}."
-            tr(f"qkv_t{i}", pre + "dec_attn.qkv_net.weight", (3 * HD, D))
-            tr(f"o_t{i}", pre + "dec_attn.o_net.weight", (D, HD))
-            tr(f"w1_t{i}", pre + "pos_ff.CoreNet.0.weight", (DI, D))
-            tr(f"w2_t{i}", pre + "pos_ff.CoreNet.3.weight", (D, DI))
+
+        def transposes():
+            tr("Et", "word_emb.emb_layers.0.weight", (V, D), VPAD)
+            for i in range(self.n_layer):
+                pre = f"layers.{i}."
+                tr(f"qkv_t{i}", pre + "dec_attn.qkv_net.weight", (3 * HD, D))
+                tr(f"o_t{i}", pre + "dec_attn.o_net.weight", (D, HD))
+                tr(f"w1_t{i}", pre + "pos_ff.CoreNet.0.weight", (DI, D))
+                tr(f"w2_t{i}", pre + "pos_ff.CoreNet.3.weight", (D, DI))
+        # The transposed shadows are read by the NEXT backward only (forward and decode use the plain bf16 copy): build
+        # them on the side stream, beside the next forward; _run_backward waits for fl["shadow_ready"].
+        if getattr(self, "wgrad_side_stream", True):
+            side = fl.get("wgrad_stream")
+            if side is None:
+                side = fl["wgrad_stream"] = torch.cuda.Stream(device=dev)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                transposes()
+                fl["shadow_ready"] = torch.cuda.Event()
+                fl["shadow_ready"].record(side)
+        else:
+            transposes()
 
     # crop / pad specification of a 2-D parameter: rows = rg groups of rt (padded to rp), cols = cg groups of ct
     # (padded to cp).  Head-structured dimensions (q|k|v thirds x heads) pad every head separately.
@@ -531,6 +548,8 @@ class MemTransformerLM(nn.Module):
         # They run on a SIDE stream, ordered after the kernels that produced their operands, so they fill the
         # tails of the attention / dX kernels on the main stream; joined before the gradients are consumed.
         main = torch.cuda.current_stream()
+        if fl.get("shadow_ready") is not None:
+            main.wait_event(fl["shadow_ready"])          # transposed weights of the last optimiser step are in place
         side = fl.get("wgrad_stream") if getattr(self, "wgrad_side_stream", True) else None
         if side is None and getattr(self, "wgrad_side_stream", True):
             side = fl["wgrad_stream"] = torch.cuda.Stream(device=dev)
