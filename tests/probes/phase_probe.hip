@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, int pad) {
 
 // "all" with the fragment reads of tile t+1 (K and band) issued right after tile t's QK/QR MFMAs, and tile t's V fragments
 // requested before the softmax: every LDS round trip sits under arithmetic.  PRE: 0 = none, 1 = V early, 2 = V early + next K/R
-template <int PRE>
+template <int PRE, bool LAZY = false>
 __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters, int pad) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
@@ -219,6 +219,27 @@ __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters, int pad
             s[2][reg] += bperm(srcaddr[reg], t2);
             s[3][reg] += bperm(srcaddr[reg], t3);
         }
+        if (LAZY) {
+            // scores already carry "- m" (folded into the accumulator initialisation): only test for growth
+            bool big = false;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                big |= fmaxf(fmaxf(s[0][reg], s[1][reg]), fmaxf(s[2][reg], s[3][reg])) > 6.f;
+            if (__any(big)) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float mx = fmaxf(fmaxf(s[0][reg], s[1][reg]), fmaxf(s[2][reg], s[3][reg]));
+                    mx = fmaxf(row16_max(mx), 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-mx);
+                    mrow[reg] += mx;
+                    lpart[reg] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) o[d][reg] *= alpha;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s[c][reg] -= mx;
+                }
+            }
+        } else {
         float mnew[4];
         bool grew = false;
 #pragma unroll
@@ -238,12 +259,13 @@ __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters, int pad
                 for (int d = 0; d < 4; ++d) o[d][reg] *= alpha;
             }
         }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 pb;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
+                const float p = LAZY ? __builtin_amdgcn_exp2f(s[c][reg]) : __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
                 lpart[reg] += p;
                 pb[reg] = (__bf16)p;
             }
@@ -281,17 +303,17 @@ __global__ __launch_bounds__(256) void probe_pipe(float* out, int iters, int pad
     for (int e = 0; e < 4; ++e) acc += lpart[e] + mrow[e] + qr[4][e] + (float)kf[0][e] + (float)rf[9][e];
     if (acc == 12345.678f) out[threadIdx.x] = acc;
 }
-template <int PRE> void run_pipe(const char* name, float* d_out) {
+template <int PRE, bool LAZY = false> void run_pipe(const char* name, float* d_out) {
     const int iters = 2000;
     for (int occ = 1; occ <= 3; ++occ) {
         const int lds = occ == 1 ? 150 * 1024 : (occ == 2 ? 78 * 1024 : 52 * 1024);
-        hipFuncSetAttribute((const void*)probe_pipe<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)probe_pipe<PRE, LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
-        probe_pipe<PRE><<<256 * occ, 256, lds>>>(d_out, 10, 0);
+        probe_pipe<PRE, LAZY><<<256 * occ, 256, lds>>>(d_out, 10, 0);
         hipDeviceSynchronize();
         hipEventRecord(a);
-        probe_pipe<PRE><<<256 * occ, 256, lds>>>(d_out, iters, 0);
+        probe_pipe<PRE, LAZY><<<256 * occ, 256, lds>>>(d_out, iters, 0);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
@@ -339,5 +361,6 @@ int main() {
     run_pipe<0>("pipe: as shipped", d_out);
     run_pipe<1>("pipe: V early", d_out);
     run_pipe<2>("pipe: V early + next K/R", d_out);
+    run_pipe<0, true>("lazy max, folded subtraction", d_out);
     return 0;
 }
