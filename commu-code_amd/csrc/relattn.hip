@@ -203,9 +203,14 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int QT = (a.T + QROWS - 1) / QROWS;
-    int qt, h, b;
-    tile_coords(QT, a.H, a.B, qt, h, b);
-    qt = QT - 1 - qt;                    // heaviest tile of a pair first
+    // A workgroup takes the query tiles q and QT-1-q of its (batch, head) pair back to back: every workgroup walks the
+    // same number of key tiles (the causal triangle folded in half), and half as many workgroups are launched.
+    const int QH = (QT + 1) / 2;
+    int qslot, h, b;
+    tile_coords(QH, a.H, a.B, qslot, h, b);
+    for (int rep = 0; rep < 2; ++rep) {
+    const int qt = rep == 0 ? QT - 1 - qslot : qslot;
+    if (rep == 1 && qt >= QT - 1 - qslot) break;          // odd tile count: the middle tile is done once
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
             if (r16 == 0) a.lse[((size_t)b * a.H + h) * T + i] = (mrow[reg] + __log2f(l)) * LN2;
         }
     }
+    }
 }
 
 // =============================================================================================
@@ -406,9 +412,12 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int QT = (a.T + QROWS - 1) / QROWS;
-    int qt, h, b;
-    tile_coords(QT, a.H, a.B, qt, h, b);
-    qt = QT - 1 - qt;                    // heaviest tile of a pair first
+    const int QH = (QT + 1) / 2;          // query tiles q and QT-1-q back to back (see relattn_fwd_kernel)
+    int qslot, h, b;
+    tile_coords(QH, a.H, a.B, qslot, h, b);
+    for (int rep = 0; rep < 2; ++rep) {
+    const int qt = rep == 0 ? QT - 1 - qslot : qslot;
+    if (rep == 1 && qt >= QT - 1 - qslot) break;
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
@@ -616,6 +625,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         for (int ww = 0; ww < NW; ++ww) acc += red[ww][tid];
         a.du_part[((size_t)b * QT + qt) * HD + h * DH + tid] = acc;
     }
+    __syncthreads();          // `red` is reused by the second tile
+    }
 }
 
 // =============================================================================================
@@ -632,8 +643,12 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
     __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
-    int jt, h, b;
-    tile_coords((a.T + a.M + KCOLS - 1) / KCOLS, a.H, a.B, jt, h, b);
+    const int NT = (a.T + a.M + KCOLS - 1) / KCOLS, NH = (NT + 1) / 2;      // key tiles j and NT-1-j back to back
+    int jslot, h, b;
+    tile_coords(NH, a.H, a.B, jslot, h, b);
+    for (int rep = 0; rep < 2; ++rep) {
+    const int jt = rep == 0 ? jslot : NT - 1 - jslot;
+    if (rep == 1 && jt <= jslot) break;
     const int j0 = jt * KCOLS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
@@ -789,6 +804,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
             }
         }
     }
+    __syncthreads();
+    }
 }
 
 // delta[b,h,i] = sum_f dO[i,b,h,f] * O[i,b,h,f]
@@ -874,7 +891,7 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
     // (the kernels are parametrised by waves per workgroup; 8-wave / 128-row tiles measured slower than 4-wave
     // tiles at every shape of this model, so only NW = 4 is instantiated)
-    dim3 grid(((d->T + 63) / 64) * d->H * d->B);
+    dim3 grid((((d->T + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
 #define ATTN_FWD(DHV)                                                                              \
     {                                                                                              \
@@ -904,7 +921,7 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     a.dsk_wedge = e->dsk_wedge;
     if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
     if (e->du_rows != (d->T + 63) / 64) return -22;
-    dim3 gq(((d->T + 63) / 64) * d->H * d->B), gk(((K + 63) / 64) * d->H * d->B);
+    dim3 gq((((d->T + 63) / 64 + 1) / 2) * d->H * d->B), gk((((K + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
 #define ATTN_BWD(DHV)                                                                                                  \
     {                                                                                                                  \
