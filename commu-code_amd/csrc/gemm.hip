@@ -67,7 +67,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w / WN, wc = w % WN, r16 = lane & 15, g = lane >> 4;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    int tm = lid / tiles_n;
+    const int tn = lid - tm * tiles_n;
+    if (bs.tri_B > 0) tm = (int)gridDim.x / tiles_n - 1 - tm;      // causal band: longest contractions (last rows) first
     const int m0 = tm * BM, n0 = tn * BN;
     A += (long long)blockIdx.y * bs.a;
     B += (long long)blockIdx.y * bs.b;
