@@ -397,6 +397,12 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
          DH, TB, DH, ld_dsk, _p(dq_ac), HD, DH, EPI_RESID, H, tri_B, tri_M, _s())
     def drd_part():
         # dRd only feeds r_net's weight gradient: `defer` (optional) runs it off the critical path (side stream)
+        if defer is not None:
+            # a call-local dS-by-distance buffer (reset / same_length masks, or no persistent scratch) must outlive
+            # this function on the deferring stream: without this the main-stream allocator may hand the block to
+            # the next layer while the GEMM below is still reading it
+            dsk.record_stream(torch.cuda.current_stream())
+            qv2.record_stream(torch.cuda.current_stream())
         ns = tn_slices(TB, ld_dsk, DH * H)
         slabs = torch.empty(H * ns * ld_dsk * DH, device=dev, dtype=F32)
         call("commu_gemm_tn_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(qv2), HD, DH, _p(slabs), DH, ld_dsk * DH, TB,

@@ -11,6 +11,7 @@
 // 4 consecutive output columns of one row: 8-byte bf16x4 / 16-byte f32x4 stores.
 #include "common.cuh"
 #include "commu_hip.h"
+#include "gemm8.cuh"
 #include <math.h>
 #include <stdlib.h>
 
@@ -575,6 +576,13 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
 #undef SK_LAUNCH
         COMMU_LAUNCH_CHECK();
         return 0;
+    }
+    if (gemm8_nt_eligible(M, N, K, lda, ldb, batch, bs.tri_B, flags)) {
+        // large-M Linear shapes: persistent 256 x 256 x 64 eight-phase kernel (gemm8.hip)
+        G8Args g8{(const bf16*)A, (const bf16*)B, C, lda, ldb, ldc, M, N, K, (M + 255) / 256, (N + 255) / 256,
+                  bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags, drop_seed,
+                  (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0), 1.f / (1.f - drop_p), mask_scale, 0, 0};
+        return launch_gemm8_nt(g8, stream);
     }
     const bool narrow = (N <= 64);
     // large M: 256 x 256 (512 threads) for wide outputs, 256 x 128 (256 threads, two workgroups per CU so one's

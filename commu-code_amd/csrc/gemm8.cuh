@@ -1,0 +1,23 @@
+// Internal interface between gemm.hip (dispatch) and gemm8.hip (the 256 x 256 x 64 eight-phase kernels).
+#pragma once
+#include "common.cuh"
+
+struct G8Args {
+    const bf16* A;
+    const bf16* B;
+    void* C;
+    int lda, ldb, ldc, M, N, K, tiles_m, tiles_n;
+    const float* bias;
+    const bf16* resid;
+    int ldr;
+    const bf16* rmask;
+    int ldm, flags;
+    unsigned drop_seed, drop_thr;
+    float drop_scale, mask_scale;
+    int store_mode;           // (experiment) 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+    int skew_cycles;          // start-up skew between the workgroups of an XCD (0: none)
+};
+
+// true when the 8-phase NT kernel takes this problem (large M, K % 64 == 0, 32-bit buffer offsets)
+bool gemm8_nt_eligible(int M, int N, int K, int lda, int ldb, int batch, int tri_B, int flags);
+int launch_gemm8_nt(const G8Args& a, hipStream_t stream);

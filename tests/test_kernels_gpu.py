@@ -81,6 +81,56 @@ def test_gemm_nt_epilogues():
     assert relerr(wide[:, 100:100 + N], ref) < BF16_TOL and float(wide[:, :100].abs().max()) == 0
 
 
+# the 256 x 256 x 64 eight-phase kernel (gemm8.hip): interior tiles, M / N tails, odd K-tile counts, a persistent
+# grid smaller than the tile count (COMMU_GEMM8_GRID), every epilogue
+@pytest.mark.parametrize("grid", [0, 3])
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 512), (2300, 729, 512), (1041, 1536, 128), (1024, 264, 192),
+                                   (4096, 1024, 1024)])
+def test_gemm_nt_eight_phase(M, N, K, grid, monkeypatch):
+    o = ops()
+    if grid:
+        monkeypatch.setenv("COMMU_GEMM8_GRID", str(grid))
+    A, B = bf(rnd(M, K, seed=21)), bf(rnd(N, K, seed=22))
+    ref = A.float() @ B.float().t()
+    ld = (N + 7) // 8 * 8
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    out = o.gemm_nt(Ad, Bd, out=torch.full((M, ld), float("nan"), device=DEV)[:, :N])
+    assert relerr(out, ref) < F32_TOL
+    out = o.gemm_nt(Ad, Bd, out=torch.full((M, ld), float("nan"), device=DEV, dtype=torch.bfloat16)[:, :N])
+    assert relerr(out, ref) < BF16_TOL
+    def buf(dtype=torch.float32):          # NaN-filled, leading dimension padded to a multiple of 8
+        return torch.full((M, ld), float("nan"), device=DEV, dtype=dtype)[:, :N]
+
+    def padded(x):                         # same for the auxiliary operands (strided views)
+        t = torch.zeros(M, ld, dtype=x.dtype, device=DEV)
+        t[:, :N] = x.to(DEV)
+        return t[:, :N]
+    bias, resid, act = rnd(N, seed=23), bf(rnd(M, N, seed=24)), bf(rnd(M, N, seed=25))
+    out = o.gemm_nt(Ad, Bd, out=buf(), bias=bias.to(DEV), relu=True)
+    assert relerr(out, torch.relu(ref + bias)) < F32_TOL
+    out = o.gemm_nt(Ad, Bd, out=buf(), bias=bias.to(DEV), resid=padded(resid))
+    assert relerr(out, ref + bias + resid.float()) < F32_TOL
+    out = o.gemm_nt(Ad, Bd, out=buf(torch.bfloat16), relu_mask=padded(act), mask_scale=1.25)
+    assert relerr(out, ref * (act.float() > 0) * 1.25) < BF16_TOL
+    # dropout epilogue: the kernel's counter-based mask, re-created on the host
+    seed, p = 12345, 0.1
+    keep = o.dropout_keep_mask(seed, M * N, p).view(M, N)
+    out = o.gemm_nt(Ad, Bd, out=buf(), resid=padded(resid), drop_p=p, drop_seed=seed)
+    assert relerr(out, ref * keep / (1 - p) + resid.float()) < F32_TOL
+
+
+def test_gemm_nt_eight_phase_asymmetric_identity():
+    """A = [I; 0...] pattern with an asymmetric B: catches transposed / permuted C writes of the 8-phase kernel."""
+    o = ops()
+    M, N, K = 1024, 512, 128
+    A = torch.zeros(M, K)
+    for m in range(M):
+        A[m, (7 * m + 3) % K] = 1.0
+    B = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 37 % 251)
+    out = o.gemm_nt(bf(A).to(DEV), bf(B).to(DEV), out_f32=True)
+    assert torch.equal(out.cpu(), bf(A).float() @ bf(B).float().t())
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 256, 192), (333, 136, 64), (4096, 768, 64), (50, 8, 8)])
 def test_gemm_tn(M, N, K, mode):
