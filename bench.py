@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="weight-gradient work on the main stream (default: a side stream)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,6 +172,8 @@ def main():
                   batch_chunk=args.batch_chunk, dropout=args.dropout, attention_dropout=args.dropout)
     model = build_model(cfg, BaseVocab(), dev, seed=cfg.TRAIN.seed)
     model.train()
+    if args.no_side_stream:
+        model.wgrad_side_stream = False
     reducer = GradReducer() if world > 1 else None
     if reducer is not None:
         reducer.broadcast_params(model)

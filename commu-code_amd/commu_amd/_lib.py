@@ -28,7 +28,11 @@ class AttnDesc(C.Structure):
 class AttnBwdDesc(C.Structure):
     _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
                 ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
-                ("du_rows", c_i), ("dsk_wedge", c_i)]
+                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i)]
+
+
+class TnProblem(C.Structure):
+    _fields_ = [("A", c_p), ("B", c_p), ("lda", c_i), ("ldb", c_i), ("N", c_i), ("K", c_i), ("out_off", C.c_longlong)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
@@ -40,6 +44,8 @@ PROTOTYPES = {
     "commu_gemm_tn_slices": [c_i, c_i, c_i],
     "commu_gemm_tn_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, c_z, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_i, c_p],
+    "commu_gemm_tn_grouped_slices": [C.POINTER(TnProblem), c_i, c_i],
+    "commu_gemm_tn_bf16_grouped": [C.POINTER(TnProblem), c_i, c_i, c_p, C.c_longlong, c_i, c_p],
     "commu_reduce_slabs2d_f32": [c_p, c_i, C.c_longlong, c_p, c_i, c_i, c_i, c_z, c_i, c_i, c_f, c_p],
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
     "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
@@ -68,6 +74,8 @@ PROTOTYPES = {
     "commu_relattn_bwd_q": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_kv": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_attn_bwd_qrows": [c_i],
+    "commu_attn_band_slabs": [c_i, c_i],
+    "commu_relattn_bwd_band": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_attn_delta": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_sample_topk": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
@@ -77,7 +85,7 @@ PROTOTYPES = {
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows"}
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs"}
 
 _lib = None
 

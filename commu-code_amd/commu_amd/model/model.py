@@ -555,15 +555,34 @@ class MemTransformerLM(nn.Module):
             side = fl["wgrad_stream"] = torch.cuda.Stream(device=dev)
         keep = []          # operands stay referenced until the join: the allocator must not hand them out early
 
+        # Weight gradients of a layer are collected and issued as ONE grouped launch of the eight-phase TN kernel
+        # (commu_gemm_tn_bf16_grouped: every token slice on its own XCD, so the layer's activations leave HBM once);
+        # problems the grouped kernel does not take (small shapes) fall back to the per-GEMM path.
+        pending = []
+
         def wgrad(dY, Xa, gW, rows=None, crop=None):
+            pending.append((dY, Xa, gW, rows, crop))
+
+        def flush_wgrads():
+            if not pending:
+                return
+            batch = list(pending)
+            pending.clear()
+            keep.extend(t for it in batch for t in it[:2])
+
+            def run():
+                groups = {}
+                for it in batch:
+                    groups.setdefault(it[0].shape[0], []).append(it)
+                for items in groups.values():
+                    self._tn_group_acc(items)
             if side is None:
-                return self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
-            keep.extend((dY, Xa))
+                return run()
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev)
-                self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
+                run()
 
         def join():
             if side is not None:
@@ -602,6 +621,7 @@ class MemTransformerLM(nn.Module):
         def ss(site):
             return ops.site_seed(sv.seed, site)
 
+        flush_wgrads()
         dy = ops.gemm_nt(dlogits, sh["Et"], drop_p=p, drop_seed=ss(2))           # [TB, D] (through the final dropout)
         gu, gvb = gv("r_w_bias", (HDt,)), gv("r_r_bias", (HDt,))
         if pad:                       # the kernels accumulate [H, DHp] rows; cropped into the gradients at the end
@@ -660,6 +680,7 @@ class MemTransformerLM(nn.Module):
             wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))
             if M > 0:
                 wgrad(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
+            flush_wgrads()
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
             hook = getattr(self, "grad_ready_hook", None)
             if hook is not None and direct:
@@ -676,6 +697,33 @@ class MemTransformerLM(nn.Module):
         if direct:
             return tuple(None for _ in params)
         return tuple(G[off:off + p.numel()].view(p.shape) for p, off in zip(params, fl["offs"]))
+
+    def _tn_group_acc(self, items):
+        """items = [(dY, X, gW, rows, crop), ...] with a common token count: gW (+)= dY^T X for each, one grouped
+        launch + one reduce per problem; falls back to _tn_acc when the grouped kernel does not take the shapes."""
+        fl = self._flat
+        arr, Mtok, offs, total = ops.tn_group([(it[0], it[1]) for it in items])
+        ns = ops.tn_group_slices(arr, Mtok) if len(items) <= 8 else 0
+        if ns <= 0:
+            for dY, Xa, gW, rows, crop in items:
+                self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
+            return
+        need = ns * total
+        if fl.get("slabs") is None or fl["slabs"].numel() < need:
+            fl["slabs"] = torch.empty(need, device=fl["dev"], dtype=F32)
+        slabs = fl["slabs"]
+        ops.gemm_tn_grouped(arr, Mtok, slabs, total, ns)
+        for (dY, Xa, gW, rows, crop), off in zip(items, offs):
+            N, Kc = dY.shape[1], Xa.shape[1]
+            if crop is not None:
+                rg, rt, rp, cg, ct, cp = crop
+                assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)
+                tmp = torch.empty(N * Kc, device=fl["dev"], dtype=F32)
+                ops.reduce_slabs(tmp, slabs[off:], N * Kc, ns, total, False, 1.0)
+                gW.view(rg, rt, cg, ct).add_(tmp.view(rg, rp, cg, cp)[:, :rt, :, :ct])
+            else:
+                nrows = N if rows is None else rows
+                ops.reduce_slabs(gW, slabs[off:], nrows * Kc, ns, total, True, 1.0)
 
     def _tn_acc(self, dY, Xa, gW, rows=None, crop=None):
         """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads.

@@ -152,6 +152,37 @@ def gemm_tn_raw(A, B, slabs, nslices, mode=None):
     return slabs
 
 
+def tn_group(pairs):
+    """ctypes problem array for a grouped weight-gradient launch: pairs = [(dY [M,N], X [M,K]), ...] (bf16, shared M).
+    Returns (array, M, offsets, total) with offsets[i] = element offset of problem i's [N, K] block inside a slab."""
+    arr = (_lib.TnProblem * len(pairs))()
+    M = pairs[0][0].shape[0]
+    offs, total = [], 0
+    for i, (A, B) in enumerate(pairs):
+        assert A.shape[0] == M and B.shape[0] == M and A.dtype == BF16 and B.dtype == BF16
+        arr[i].A, arr[i].B = A.data_ptr(), B.data_ptr()
+        arr[i].lda, arr[i].ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
+        arr[i].N, arr[i].K = A.shape[1], B.shape[1]
+        arr[i].out_off = total
+        offs.append(total)
+        total += A.shape[1] * B.shape[1]
+    return arr, M, offs, total
+
+
+def tn_group_slices(arr, M):
+    """Token slices the grouped kernel wants for this group (0: not eligible -> per-problem commu_gemm_tn_bf16)."""
+    return _lib.load().commu_gemm_tn_grouped_slices(arr, len(arr), int(M))
+
+
+def gemm_tn_grouped(arr, M, slabs, slab_stride, nslices):
+    """slabs[s * slab_stride + off_p + n*K_p + k] = sum over token slice s of A_p[m,n] B_p[m,k], one launch."""
+    if not slabs.is_cuda:
+        raise CommuHipError("commu_amd kernels need GPU tensors (no CPU fallback)")
+    assert slabs.dtype == F32 and slabs.numel() >= nslices * slab_stride
+    call("commu_gemm_tn_bf16_grouped", arr, len(arr), int(M), _p(slabs), int(slab_stride), int(nslices), _s())
+    return slabs
+
+
 def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate, alpha=1.0):
     """dst.view(-1)[:n] = (accumulate ? dst : 0) + alpha * sum_s slabs[s*stride : s*stride + n]"""
     assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() >= n
@@ -339,6 +370,7 @@ def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
 
 
 POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prove nothing reads it
+NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead of commu_relattn_bwd_band
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
@@ -353,7 +385,9 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     qu2, qv2 = qs
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
     call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
-    ld_dsk = round_up(K, 32)
+    # fused band pass (commu_relattn_bwd_band: dq_BD and dRd in ONE sweep over dS-by-distance) when the shape allows
+    band_slabs = call("commu_attn_band_slabs", T, B) if (DH == 64 and K <= 1024 and not NO_FUSED_BAND) else 0
+    ld_dsk = round_up(K, 128) if band_slabs else round_up(K, 32)
     # dS by distance is lower-triangular (d <= i + M).  Without same_length / reset masks the two GEMMs below only
     # visit the band (half the work) and the kernel only writes the triangle.  What lies right of the causal edge
     # must read as zero: either the kernel also writes a wedge of zeros as wide as a GEMM tile can overhang
@@ -368,7 +402,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
             scratch["dsk"] = torch.zeros(H, T * B, ld_dsk, device=dev, dtype=BF16)
         dsk, wedge = scratch["dsk"], 0
     elif band:
-        wedge = 136 + (128 + B - 1) // B
+        # (zeros right of the causal edge, as wide as a GEMM tile / a 256-distance chunk of the fused pass overhangs)
+        wedge = (136 + (64 + B - 1) // B) if band_slabs else (136 + (128 + B - 1) // B)
         dsk = torch.empty(H, T * B, ld_dsk, device=dev, dtype=BF16)
         if POISON_SCRATCH:
             dsk.fill_(float("nan"))
@@ -386,13 +421,34 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     e.dq_ac, e.dk, e.dv = dq_ac.data_ptr(), dk.data_ptr(), dv.data_ptr()
     e.dsk, e.du_part = dsk.data_ptr(), du_part.data_ptr()
     e.ld_dqkv, e.ld_dsk, e.du_rows, e.dsk_wedge = dk.stride(0), ld_dsk, QT, wedge
+    e.dsk_tiled = 1 if band_slabs else 0
+    import os as _os
+    if _os.environ.get("COMMU_ABL_DSK"):          # profiling ablation: bwd_q without its dS-by-distance stores
+        e.dsk_wedge = -7
     assert dv.stride(0) == dk.stride(0)
     call("commu_relattn_bwd_q", C.byref(d), C.byref(e), _s())
     call("commu_relattn_bwd_kv", C.byref(d), C.byref(e), _s())
-    # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
-    rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
     c2 = d.scale * 1.4426950408889634
     TB = T * B
+    if band_slabs:
+        # one pass: dq = dq_ac + dsk . Rd on this stream; the dRd partial slabs are reduced off the critical path
+        slabs = torch.empty(H * band_slabs * 1024 * DH, device=dev, dtype=F32)
+        call("commu_relattn_bwd_band", _p(dsk), ld_dsk, _p(rd), rd.stride(0), _p(qv2), qv2.stride(0), _p(dq_ac), HD,
+             _p(dq), dq.stride(0), _p(slabs), T, M, B, H, DH, 1 if band else 0, _s())
+
+        def drd_reduce():
+            if defer is not None:
+                slabs.record_stream(torch.cuda.current_stream())
+            call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, band_slabs, 1024 * DH, H, 0,
+                 1.0 / c2, _s())
+        if defer is None:
+            drd_reduce()
+        else:
+            defer(drd_reduce)
+        _bias_grads(dq, du_part, du, dvb, HD, dev, defer)
+        return delta
+    # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
+    rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
     call("commu_gemm_nt_bf16_batched", _p(dsk), ld_dsk, TB * ld_dsk, _p(rdt), ld_dsk, DH * ld_dsk, _p(dq), dq.stride(0),
          DH, TB, DH, ld_dsk, _p(dq_ac), HD, DH, EPI_RESID, H, tri_B, tri_M, _s())
     def drd_part():
@@ -412,9 +468,14 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         drd_part()
     else:
         defer(drd_part)
+    _bias_grads(dq, du_part, du, dvb, HD, dev, defer)
+    return delta
+
+
+def _bias_grads(dq, du_part, du, dvb, HD, dev, defer):
+    """d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)   (gradients only: deferrable)"""
     def bias_part():
-        # d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)   (gradients only: deferrable)
-        if defer is not None:          # local scratch outlives this function on the deferring stream
+        if defer is not None:          # local scratch outlives the caller on the deferring stream
             du_part.record_stream(torch.cuda.current_stream())
         ca = torch.zeros(HD, device=dev, dtype=F32)
         colsum(du_part, ca)
@@ -426,7 +487,6 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         bias_part()
     else:
         defer(bias_part)
-    return delta
 
 
 def sample_topk(logits, temperature, top_k, wrong=None, uniforms=None, active=None, token=None, probs_out=None):

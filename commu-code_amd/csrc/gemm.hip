@@ -732,3 +732,42 @@ extern "C" int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch
     COMMU_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- grouped weight-gradient GEMM (gemm8.hip: gemm_tn8_kernel)
+static bool tn_group_plan(const commu_tn_problem* probs, int nprob, int M, Tn8Args* out) {
+    if (nprob <= 0 || nprob > 8) return false;
+    int tiles = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const commu_tn_problem& q = probs[i];
+        if (!gemm8_tn_eligible(M, q.N, q.K, q.lda, q.ldb)) return false;
+        Tn8Prob& t = out->p[i];
+        t.A = (const bf16*)q.A; t.B = (const bf16*)q.B; t.lda = q.lda; t.ldb = q.ldb; t.N = q.N; t.Kc = q.K;
+        t.tiles_n = (q.N + 255) / 256; t.tiles_k = (q.K + 255) / 256; t.tile0 = tiles; t.out_off = q.out_off;
+        tiles += t.tiles_n * t.tiles_k;
+    }
+    out->nprob = nprob; out->M = M; out->total_tiles = tiles;
+    return true;
+}
+
+extern "C" int commu_gemm_tn_grouped_slices(const commu_tn_problem* probs, int nprob, int M) {
+    Tn8Args a;
+    if (!tn_group_plan(probs, nprob, M, &a)) return 0;
+    // one workgroup per CU: tiles x slices <= 256, slices a multiple of 8 when possible (one slice per XCD)
+    int s = 256 / a.total_tiles;
+    if (s >= 8) s &= ~7;
+    if (s < 1) s = 1;
+    const int cap = (M + 1023) / 1024;          // at least 16 K-tiles per workgroup
+    if (s > cap) s = cap;
+    return s;
+}
+
+extern "C" int commu_gemm_tn_bf16_grouped(const commu_tn_problem* probs, int nprob, int M, float* slabs,
+                                          long long slab_stride, int nslices, hipStream_t stream) {
+    Tn8Args a;
+    if (nslices <= 0 || !tn_group_plan(probs, nprob, M, &a)) return -22;
+    a.nslices = nslices;
+    a.m_per_slice = (((M + nslices - 1) / nslices) + 63) / 64 * 64;
+    a.slabs = slabs;
+    a.slab_stride = slab_stride;
+    return launch_gemm8_tn(a, stream);
+}

@@ -389,6 +389,226 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
 #undef G8_MFMA
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// gemm_tn8: the same eight-phase pipeline for the weight gradients dW[n, k] = sum_m dY[m, n] * X[m, k]
+// (autograd of every nn.Linear of commu/model/model.py:163-169,205,212,278; contraction over the tokens).
+//  * Both operands have the contraction index m as their ROW index: a K-tile is 64 rows (m) of two 256-column
+//    images; half-tiles are [64 m][128 columns] (256-byte rows: lo = tile columns 0..127, hi = 128..255), so every
+//    DMA piece (4 rows x 256 bytes) reads whole 128-byte lines.  MFMA fragments (8 consecutive m of one column) come
+//    from ds_read_b64_tr_b16 transpose reads; 32-byte unit index XOR (m & 3) | ((m >> 3) & 1) << 2 keeps the 8 rows of
+//    a half-wave on 8 different bank groups.
+//  * One launch covers up to 8 problems (all weight gradients of a layer) x nslices token slices; workgroup =
+//    (slice, tile), slice-major ids + the XCD remap put every slice on ONE XCD: the 32 workgroups of an XCD
+//    read the same token rows (of all problems) at the same time -> each activation byte leaves HBM once.
+//  * Output: fp32 slab [slice][problem block] (summed by commu_reduce_slabs_f32), 16-byte stores.
+struct TnTile {
+    int prob, n0, k0;
+};
+
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3, r16 = lane & 15, g = lane >> 4;
+
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int slice = lid / a.total_tiles, tile = lid - slice * a.total_tiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < a.nprob && tile >= a.p[i].tile0) pi = i;
+    // (uniform select of the problem record; the fields are kernel arguments -> scalar registers)
+    const bf16* Ap = a.p[0].A;
+    const bf16* Bp = a.p[0].B;
+    int lda = a.p[0].lda, ldb = a.p[0].ldb, N = a.p[0].N, Kc = a.p[0].Kc, tiles_k = a.p[0].tiles_k, tile0 = 0;
+    long long out_off = a.p[0].out_off;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (pi == i) {
+            Ap = a.p[i].A; Bp = a.p[i].B; lda = a.p[i].lda; ldb = a.p[i].ldb; N = a.p[i].N; Kc = a.p[i].Kc;
+            tiles_k = a.p[i].tiles_k; tile0 = a.p[i].tile0; out_off = a.p[i].out_off;
+        }
+    const int tl = tile - tile0;
+    const int n0 = (tl / tiles_k) * 256, k0 = (tl % tiles_k) * 256;
+    const int mbeg = slice * a.m_per_slice;
+    const int mend = min(a.M, mbeg + a.m_per_slice);
+    const int nsteps = mend > mbeg ? (mend - mbeg + 63) >> 6 : 0;
+
+    // ---- staging: piece j of wave w = half-tile rows 8 w + 4 j + (lane >> 4); LDS slot lane & 15 of the 256-byte row
+    // holds logical 16-byte chunk c: unit (c >> 1) = (slot >> 1) ^ f(row)
+    unsigned voffX[2][2], voffW[2][2];          // [lo / hi][piece]; columns beyond N / Kc are pushed out of range
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 8 * w + 4 * j + (lane >> 4);
+        const int slot = lane & 15;
+        const int f = (row & 3) | (((row >> 3) & 1) << 2);
+        const int c = ((((slot >> 1) ^ f) << 1) | (slot & 1)) * 8;          // first column of the chunk inside the half
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            voffX[hi][j] = (n0 + 128 * hi + c < N) ? (unsigned)(row * lda + c) * 2u : 0x80000000u;
+            voffW[hi][j] = (k0 + 128 * hi + c < Kc) ? (unsigned)(row * ldb + c) * 2u : 0x80000000u;
+        }
+    }
+    const int rows_left = mend - mbeg;
+    auto mk = [&](const bf16* base, int ld, int col0) {
+        const unsigned nrec = rows_left > 0 ? (unsigned)(((size_t)(rows_left - 1) * ld + 128) * 2) : 0u;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)mbeg * ld + col0), 0, (int)nrec, 0x00020000);
+    };
+    const srd_t sXlo = mk(Ap, lda, n0), sXhi = mk(Ap, lda, n0 + 128), sWlo = mk(Bp, ldb, k0), sWhi = mk(Bp, ldb, k0 + 128);
+    const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
+    auto stage = [&](int q, int step, int pb) {
+        const unsigned dst = lds0 + pb * BUF_BYTES + q * HT_BYTES + w * 2048;
+        if (q == Q_XLO) { const unsigned so = (unsigned)step * 128u * (unsigned)lda; dma16(sXlo, voffX[0][0], so, dst); dma16(sXlo, voffX[0][1], so, dst + 1024); }
+        else if (q == Q_XHI) { const unsigned so = (unsigned)step * 128u * (unsigned)lda; dma16(sXhi, voffX[1][0], so, dst); dma16(sXhi, voffX[1][1], so, dst + 1024); }
+        else if (q == Q_WLO) { const unsigned so = (unsigned)step * 128u * (unsigned)ldb; dma16(sWlo, voffW[0][0], so, dst); dma16(sWlo, voffW[0][1], so, dst + 1024); }
+        else { const unsigned so = (unsigned)step * 128u * (unsigned)ldb; dma16(sWhi, voffW[1][0], so, dst); dma16(sWhi, voffW[1][1], so, dst + 1024); }
+    };
+
+    // ---- fragments: lane (i = r16, g) supplies &img[32 ks + 8 g + (i >> 2) + 4 h][16-column block, + 4 (i & 3)]
+    const LDS_AS char* lds = (const LDS_AS char*)smem;
+    const int fi = ((r16 >> 2) & 3) | ((g & 1) << 2);
+    const int lanebase = (8 * g + (r16 >> 2)) * 256 + (r16 & 3) * 8;
+    int xoff[4], woff[2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xoff[b] = lanebase + (((4 * wr + b) ^ fi) << 5);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) woff[b] = lanebase + (((2 * wc + b) ^ fi) << 5);
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    auto frag = [&](int off) -> bf16x8 {          // two transpose reads: m = 8g .. 8g+3 and 8g+4 .. 8g+7
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(lds + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(lds + off + 1024));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nsteps > 0) {
+        stage(Q_XLO, 0, 0);
+        stage(Q_WHI, 0, 0);
+        stage(Q_XHI, 0, 0);
+        stage(Q_WLO, 0, 0);
+        if (nsteps > 1) {
+            stage(Q_XLO, 1, 1);
+            stage(Q_WHI, 1, 1);
+            stage(Q_XHI, 1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    G8_BAR();
+    if (wr == 1) G8_BAR();
+
+    bf16x8 xf[4][2], wf[2][2];
+    for (int st = 0; st < nsteps; ++st) {
+        const int pb = st & 1, pbo = pb * BUF_BYTES;
+        const bool v1 = st + 1 < nsteps, v2 = st + 2 < nsteps;
+        // ---- phase 1: (Xlo, Wlo)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            wf[b][0] = frag(pbo + Q_WLO * HT_BYTES + woff[b]);
+            wf[b][1] = frag(pbo + Q_WLO * HT_BYTES + woff[b] + 8192);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            xf[b][0] = frag(pbo + Q_XLO * HT_BYTES + xoff[b]);
+            xf[b][1] = frag(pbo + Q_XLO * HT_BYTES + xoff[b] + 8192);
+        }
+        if (v1) stage(Q_WLO, st + 1, pb ^ 1);
+        G8_WAIT_LGKM();
+        G8_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni][kk], xf[mi][kk], acc[ni][mi]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BAR();
+        // ---- phase 2: (Xlo, Whi)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            wf[b][0] = frag(pbo + Q_WHI * HT_BYTES + woff[b]);
+            wf[b][1] = frag(pbo + Q_WHI * HT_BYTES + woff[b] + 8192);
+        }
+        if (v2) stage(Q_XLO, st + 2, pb);
+        G8_WAIT_LGKM();
+        G8_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[2 + ni][mi] = mfma16(wf[ni][kk], xf[mi][kk], acc[2 + ni][mi]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BAR();
+        // ---- phase 3: (Xhi, Whi)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            xf[b][0] = frag(pbo + Q_XHI * HT_BYTES + xoff[b]);
+            xf[b][1] = frag(pbo + Q_XHI * HT_BYTES + xoff[b] + 8192);
+        }
+        if (v2) stage(Q_WHI, st + 2, pb);
+        G8_WAIT_LGKM();
+        G8_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[2 + ni][4 + mi] = mfma16(wf[ni][kk], xf[mi][kk], acc[2 + ni][4 + mi]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BAR();
+        // ---- phase 4: (Xhi, Wlo)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            wf[b][0] = frag(pbo + Q_WLO * HT_BYTES + woff[b]);
+            wf[b][1] = frag(pbo + Q_WLO * HT_BYTES + woff[b] + 8192);
+        }
+        if (v2) {
+            stage(Q_XHI, st + 2, pb);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        G8_WAIT_LGKM();
+        G8_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][4 + mi] = mfma16(wf[ni][kk], xf[mi][kk], acc[ni][4 + mi]);
+        __builtin_amdgcn_s_setprio(0);
+        G8_BAR();
+    }
+    if (wr == 0) G8_BAR();
+
+    // ---- slab store: lane holds out[n = .. + r16][k = .. + 4 g + reg]
+    float* out = a.slabs + (size_t)slice * a.slab_stride + out_off;
+#pragma unroll
+    for (int xb = 0; xb < 8; ++xb) {
+        const int n = n0 + 128 * (xb >> 2) + 64 * wr + 16 * (xb & 3) + r16;
+        if (n >= N) continue;
+#pragma unroll
+        for (int wb = 0; wb < 4; ++wb) {
+            const int k = k0 + 128 * (wb >> 1) + 32 * wc + 16 * (wb & 1) + 4 * g;
+            if (k < Kc) *(f32x4*)(out + (size_t)n * Kc + k) = acc[wb][xb];
+        }
+    }
+}
+
 }  // namespace
 
 bool gemm8_nt_eligible(int M, int N, int K, int lda, int ldb, int batch, int tri_B, int flags) {
@@ -428,6 +648,21 @@ int launch_gemm8_nt(const G8Args& a_in, hipStream_t stream) {
         }
     }
 #undef G8_LAUNCH
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm8_tn_eligible(int M, int N, int Kc, int lda, int ldb) {
+    if (getenv("COMMU_TN8_OFF")) return false;
+    if (M < 4096 || N < 128 || Kc < 128 || (N % 8) || (Kc % 8) || (lda % 8) || (ldb % 8)) return false;
+    if (lda < 128 || ldb < 128) return false;
+    if ((size_t)M * lda * 2 >= 0x7FFF0000ull || (size_t)M * ldb * 2 >= 0x7FFF0000ull) return false;
+    return true;
+}
+
+int launch_gemm8_tn(const Tn8Args& a, hipStream_t stream) {
+    if (a.total_tiles <= 0 || a.nslices <= 0) return 0;
+    COMMU_LAUNCH(gemm_tn8_kernel, dim3(a.total_tiles * a.nslices), dim3(512), 0, stream, a);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

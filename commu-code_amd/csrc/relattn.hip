@@ -50,6 +50,7 @@ struct AttnArgs {
     float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
     int dsk_wedge;      // > 0: dsk is uninitialised; zero columns i+M+1 .. i+M+dsk_wedge of every row (band GEMM contract)
+    int dsk_tiled;      // != 0: dsk is stored as [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (band.hip)
     int T, M, B, H;
     int same_length, sshift;
     float scale;
@@ -409,12 +410,19 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sD[NW * 64 * PT];
     __shared__ float red[NW][DH];
+    // dS-by-distance leaves through a per-wave ring [16 rows][96 distances] (distance mod 96): the un-skewed values land
+    // here 2 bytes at a time and go to HBM as whole aligned 16-byte chunks, 8 per row and key tile (the chunks the
+    // tile completed) -- 2 store instructions per wave and tile instead of 20 two-byte ones.  16-byte chunk index XOR
+    // (row >> 2) keeps the four row groups of a write on different banks.
+    constexpr int SRING = 96;
+    __shared__ __attribute__((aligned(16))) bf16 sS[NW * 16 * SRING];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int QT = (a.T + QROWS - 1) / QROWS;
     const int QH = (QT + 1) / 2;          // query tiles q and QT-1-q back to back (see relattn_fwd_kernel)
     int qslot, h, b;
     tile_coords(QH, a.H, a.B, qslot, h, b);
+    bf16* myS = sS + w * 16 * SRING;
     for (int rep = 0; rep < 2; ++rep) {
     const int qt = rep == 0 ? QT - 1 - qslot : qslot;
     if (rep == 1 && qt >= QT - 1 - qslot) break;
@@ -454,6 +462,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     int jt_lo, jt_hi;
     kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
     bf16* myD = sD + w * 64 * PT;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) *(bf16x8*)(myS + (lane + 64 * n) * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 
     const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
     const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
@@ -563,18 +573,41 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             const float v2 = lower[reg] ? e2 : e1;
             const float v3 = lower[reg] ? e1 : e0;
             const float v4 = lower[reg] ? e0 : 0.f;
-            if (i < T) {
-                bf16* drow = a.dsk + ((size_t)h * mrow0 + (size_t)i * B + b) * a.ld_dsk;
+            {
                 const int jj0 = row + 63 - r16;          // jj of block 0; block blk: jj0 - 16*blk
                 const int d0 = dlo_w + r16;
+                bf16* srow = myS + row * SRING;
 #define COMMU_DSK_STORE(BLK, VAL)                                                           \
                 {                                                                            \
-                    const int jj = jj0 - 16 * (BLK), d = d0 + 16 * (BLK);                    \
-                    if (jj >= 0 && jj <= 63 && d >= 0 && d < K) drow[d] = f2bf(VAL);         \
+                    const int jj = jj0 - 16 * (BLK);                                         \
+                    const unsigned col = (unsigned)(d0 + 16 * (BLK) + 16 * SRING) % SRING;   \
+                    if (jj >= 0 && jj <= 63) srow[(((col >> 3) ^ g) << 3) | (col & 7)] = f2bf(VAL);          \
                 }
                 COMMU_DSK_STORE(0, v0) COMMU_DSK_STORE(1, v1) COMMU_DSK_STORE(2, v2) COMMU_DSK_STORE(3, v3)
                 COMMU_DSK_STORE(4, v4)
 #undef COMMU_DSK_STORE
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // flush: row r (distance dl = i + M - j0 at jj = 0) completed the aligned chunks 8c in [dl - 63, dl]
+        if (a.dsk_wedge != -7) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int row = lane >> 2, i = iw_lo + row;
+                const int dl = i + M - j0;
+                const int c = ((dl - 56) >> 3) + (lane & 3) + 4 * n;          // ceil((dl - 63) / 8) + k
+                if (i < T && c >= 0 && 8 * c <= dl) {
+                    const unsigned col = (unsigned)(8 * c) % SRING;
+                    const bf16x8 v8 = *(const bf16x8*)(myS + row * SRING + (((col >> 3) ^ (row >> 2)) << 3));
+                    const size_t m = (size_t)i * B + b;
+                    bf16* dst;
+                    if (a.dsk_tiled)
+                        dst = a.dsk + ((((size_t)h * (mrow0 >> 6) + (m >> 6)) * (a.ld_dsk >> 7) + (c >> 4)) << 13) +
+                              ((m & 63) << 7) + ((8 * c) & 127);
+                    else
+                        dst = a.dsk + ((size_t)h * mrow0 + m) * a.ld_dsk + 8 * c;
+                    *(bf16x8*)dst = v8;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -593,13 +626,18 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         }
         __syncthreads();
     }
-    if (a.dsk_wedge > 0) {          // zeros right of the causal edge, as far as the band GEMMs read
+    if (a.dsk_wedge > 0) {          // zeros right of the causal edge, as far as the band pass / GEMMs read
         for (int r = 0; r < 16; ++r) {
             const int i = iw_lo + r;
             if (i >= T) break;
-            bf16* drow = a.dsk + ((size_t)h * mrow0 + (size_t)i * B + b) * a.ld_dsk;
+            const size_t m = (size_t)i * B + b;
             const int dbeg = i + M + 1, dend = min(a.ld_dsk, dbeg + a.dsk_wedge);
-            for (int d = dbeg + lane; d < dend; d += 64) drow[d] = f2bf(0.f);
+            for (int d = dbeg + lane; d < dend; d += 64) {
+                bf16* dst = a.dsk_tiled
+                    ? a.dsk + ((((size_t)h * (mrow0 >> 6) + (m >> 6)) * (a.ld_dsk >> 7) + (d >> 7)) << 13) + ((m & 63) << 7) + (d & 127)
+                    : a.dsk + ((size_t)h * mrow0 + m) * a.ld_dsk + d;
+                *dst = f2bf(0.f);
+            }
         }
     }
 #pragma unroll
@@ -919,7 +957,9 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     a.dsk = (bf16*)e->dsk; a.du_part = e->du_part;
     a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk;
     a.dsk_wedge = e->dsk_wedge;
+    a.dsk_tiled = e->dsk_tiled;
     if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
+    if ((e->ld_dsk % 8) || (a.dsk_tiled && ((e->ld_dsk % 128) || (((long long)d->T * d->B) % 64)))) return -22;
     if (e->du_rows != (d->T + 63) / 64) return -22;
     dim3 gq((((d->T + 63) / 64 + 1) / 2) * d->H * d->B), gk((((K + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;

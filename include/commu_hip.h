@@ -61,6 +61,21 @@ int commu_gemm_tn_slices(int M, int N, int K);
 int commu_gemm_tn_bf16_batched(const void* A, int lda, long long strideA, const void* B, int ldb,
                                long long strideB, float* slabs, int ldc, size_t slab_stride, int M, int N, int K,
                                int nslices, int batch, int tri_B, int tri_M, hipStream_t stream);
+/* Grouped form for the weight gradients of a layer (autograd of the nn.Linear calls at model.py:163-169,205,212):
+ * up to 8 problems out_p[N_p, K_p] = A_p[M, N_p]^T . B_p[M, K_p] sharing the token count M, ONE launch of the
+ * 256 x 256 x 64 eight-phase kernel over (token slice, output tile) workgroups; slice s of problem p lands at
+ * slabs[s * slab_stride + out_off_p + n * K_p + k] and is summed by commu_reduce_slabs_f32.
+ * N_p, K_p >= 128 and % 8 == 0, lda/ldb % 8 == 0 and >= 128, M >= 4096 (else -22: use commu_gemm_tn_bf16). */
+typedef struct commu_tn_problem {
+    const void* A;      /* bf16 [M][lda]  (dY)          */
+    const void* B;      /* bf16 [M][ldb]  (layer input) */
+    int lda, ldb, N, K;
+    long long out_off;  /* element offset of this problem's [N, K] block inside a slab */
+} commu_tn_problem;
+/* number of token slices that fills the 256 CUs for this group (0: a problem is not eligible) */
+int commu_gemm_tn_grouped_slices(const commu_tn_problem* probs, int nprob, int M);
+int commu_gemm_tn_bf16_grouped(const commu_tn_problem* probs, int nprob, int M, float* slabs,
+                               long long slab_stride, int nslices, hipStream_t stream);
 /* dst[z][r*ldd + c] = (accumulate ? dst : 0) + alpha * sum_s src[(z*nslabs + s)*stride + r*cols + c] */
 int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, const float* src, int rows, int cols,
                              int nslabs, size_t stride, int batch, int accumulate, float alpha, hipStream_t stream);
@@ -174,6 +189,8 @@ typedef struct commu_attn_bwd_desc {
     int ld_dqkv, ld_dsk;
     int du_rows;          /* = ceil(T / commu_attn_bwd_qrows(T)) */
     int dsk_wedge;
+    int dsk_tiled;        /* != 0: dsk is [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (the layout
+                             commu_relattn_bwd_band reads; needs (T*B) % 64 == 0, ld_dsk % 128 == 0); 0: row-major */
 } commu_attn_bwd_desc;
 int commu_attn_bwd_qrows(int T);
 int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
@@ -181,6 +198,18 @@ int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hi
  * (dk, dv); same descriptors */
 int commu_relattn_bwd_q(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 int commu_relattn_bwd_kv(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
+/* The two per-head GEMMs above fused into ONE pass over dsk (band.hip): dq = dq_ac + dsk . Rd (bf16, written in
+ * place with row stride ld_dq) and slabs[(h * P + p)][1024][64] = partial dsk^T . qv2 of token-slice pair p, with
+ * P = commu_attn_band_slabs(T, B); the caller finishes with
+ *   commu_reduce_slabs2d_f32(dRd, ld, 64, slabs, K, 64, P, 1024 * 64, H, 0, 1 / (scale * log2 e)).
+ * dsk must be TILED (commu_attn_bwd_desc.dsk_tiled).  Needs DH == 64, T + M <= 1024, ld_dsk % 128 == 0, (T * B) % 64 == 0
+ * and >= 8192 (else -22: use the two GEMMs on a row-major dsk).
+ * band != 0: rows are causal (see commu_gemm_nt_bf16_batched, tri_B = B, tri_M = M) and only the chunks of 256
+ * distances that reach the causal edge are read; what lies beyond the edge inside them must be zero. */
+int commu_attn_band_slabs(int T, int B);
+int commu_relattn_bwd_band(const void* dsk, int ld_dsk, const void* rd, int ld_rd, const void* qv2, int ld_qv,
+                           const void* dq_ac, int ld_ac, void* dq, int ld_dq, float* slabs, int T, int M, int B,
+                           int H, int DH, int band, hipStream_t stream);
 int commu_attn_delta(const void* o, const void* dout, int ld, float* delta, int T, int B, int H, int DH,
                      hipStream_t stream);
 /* dst[((b*H+h)*DH+f)*W + off + j] = src[(j*B+b)*ld + h*DH + f] (+ bias[h*DH+f]); zero elsewhere */

@@ -144,6 +144,49 @@ def test_gemm_tn(M, N, K, mode):
     assert relerr(out, 2 * ref) < F32_TOL
 
 
+@pytest.mark.parametrize("M", [4096, 5000])
+def test_gemm_tn_grouped_eight_phase(M):
+    """All weight gradients of a layer in ONE launch of the eight-phase TN kernel (gemm8.hip): mixed shapes, a
+    partial output tile (N = 328), a strided operand view, token-slice tails (M = 5000)."""
+    o = ops()
+    wide = bf(rnd(M, 1536, seed=30))
+    shapes = [(1536, 512), (512, 512), (1024, 512), (512, 1024), (328, 136)]
+    pairs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        A = wide[:, :N] if i == 0 else bf(rnd(M, N, seed=31 + i))
+        B = bf(rnd(M, K, seed=41 + i))
+        refs.append(A.float().t() @ B.float())
+        pairs.append((A.to(DEV) if i else wide.to(DEV)[:, :N], B.to(DEV)))
+    arr, Mm, offs, total = o.tn_group(pairs)
+    ns = o.tn_group_slices(arr, Mm)
+    assert ns >= 1
+    for nslices in sorted({ns, 3}):
+        slabs = torch.full((nslices * total,), float("nan"), device=DEV)
+        o.gemm_tn_grouped(arr, Mm, slabs, total, nslices)
+        for (N, K), off, ref in zip(shapes, offs, refs):
+            out = torch.zeros(N, K, device=DEV)
+            o.reduce_slabs(out, slabs[off:], N * K, nslices, total, False)
+            assert relerr(out, ref) < F32_TOL, (N, K, nslices)
+
+
+def test_gemm_tn_grouped_asymmetric():
+    o = ops()
+    M, N, K = 4096, 256, 384
+    A = torch.zeros(M, N)
+    B = torch.zeros(M, K)
+    for m in range(M):
+        A[m, (3 * m) % N] = 1.0
+        B[m, (5 * m + 1) % K] = float((m % 61) + 1)
+    ref = A.t() @ B
+    Ad, Bd = bf(A).to(DEV), bf(B).to(DEV)          # (the problem array holds raw pointers: keep the operands alive)
+    arr, Mm, offs, total = o.tn_group([(Ad, Bd)])
+    slabs = torch.zeros(4 * total, device=DEV)
+    o.gemm_tn_grouped(arr, Mm, slabs, total, 4)
+    out = torch.zeros(N, K, device=DEV)
+    o.reduce_slabs(out, slabs, N * K, 4, total, False)
+    assert torch.equal(out.cpu(), ref)
+
+
 def test_gemm_tn_asymmetric():
     o = ops()
     M, N, K = 32, 128, 128
@@ -317,6 +360,11 @@ ATTN_CASES = [
     (300, 40, 3, 1, 64, False, 40, None),
     (520, 0, 1, 2, 32, False, 0, None),
     (257, 31, 5, 1, 64, False, 31, None),
+    # >= 8192 token rows: the backward takes the fused band pass (commu_relattn_bwd_band) -- causal band with and
+    # without memory (poisoned scratch beyond the wedge), and the fully zero-initialised variant (masks)
+    (128, 0, 64, 2, 64, False, 0, None),
+    (160, 130, 52, 1, 64, False, 130, None),
+    (96, 32, 96, 2, 64, True, 100, 3),
 ]
 
 
