@@ -82,10 +82,15 @@ PROTOTYPES = {
     "commu_decode_kv_append": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_decode_attn": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
+    "commu_forcing_state_ints": [],
+    "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs"}
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
+            "commu_forcing_state_ints"}
 
 _lib = None
 

@@ -1,29 +1,28 @@
-"""Batched autoregressive generation: `num_generate` sequences decoded in parallel on one GPU with a
-per-layer K/V cache, ragged per-sequence lengths and the reference's chord-forcing rules applied
-per sequence (commu/midi_generator/midi_inferrer.py:239-354; the reference itself generates one
-sequence at a time, batch 1).
+"""Batched autoregressive generation: `num_generate` sequences decoded in parallel on one GPU with a per-layer
+K/V cache, ragged per-sequence lengths and the reference's chord / bar forcing applied per sequence
+(commu/midi_generator/midi_inferrer.py:239-354; the reference itself generates one sequence at a time, batch 1).
 
-Per loop iteration every live sequence does exactly what one iteration of the reference's
-`generate_sequence` does for it: at most one model step (with its memory kept or discarded,
-quirks Q3/Q4) and at most one draw (from fresh logits, or from the logits it already divided by
-the temperature when the previous draw was a rejected chord, quirk Q5).  The model steps of all
-sequences that need one are ONE batched decode step; the draws are ONE sampling kernel; the token
-ids come back with one host synchronisation per iteration.
+The whole loop iteration lives on the device: the forcing rules are a per-sequence state record advanced by two
+small kernels (csrc/forcing.hip), between them the batched decode step and the sampling kernel.  One iteration =
+one replay of a hipGraph; the host only polls the `done` flags every few iterations.  Per iteration every live
+sequence does exactly what one iteration of the reference's `generate_sequence` does for it: at most one model
+step (memory kept or discarded, quirks Q3/Q4) and at most one draw (from fresh logits, or from the logits already
+divided by the temperature when the previous draw was a rejected chord, quirk Q5).
 """
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import ops
-from ._lib import call
-from .midi_generator.midi_inferrer import TOKEN_OFFSET, TeacherForceTask
+from ._lib import CommuHipError, call
+from .midi_generator.midi_inferrer import TOKEN_OFFSET, ForcingReport
 
 BF16, F32 = torch.bfloat16, torch.float32
+VPAD = 768
 
 
 def _p(t):
@@ -37,7 +36,12 @@ def _s():
 class DecodeState:
     """K/V caches + distance-indexed R tables for B sequences of up to Lmax positions."""
 
+    MAX_POSITIONS = 4224          # cache rows the decode attention kernel supports (commu_decode_attn)
+
     def __init__(self, model, B: int, Lmax: int):
+        if Lmax > self.MAX_POSITIONS:
+            raise CommuHipError(f"decode cache of {Lmax} positions requested; this build supports {self.MAX_POSITIONS} "
+                                "(the reference's 1 + 4146 fits)")
         fl = model._ensure_flat()
         dev = fl["dev"]
         self.model, self.B, self.Lmax = model, B, Lmax
@@ -50,7 +54,8 @@ class DecodeState:
         self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
         pd = ops.posemb(model.pos_emb.inv_freq, Lmax, model.d_model, ld=D)
         self.rd = [ops.gemm_nt(pd, model._weights(i)["r"]) for i in range(L)]
-        self.logits = torch.zeros(B, 768, device=dev, dtype=F32)
+        self.logits = torch.zeros(B, VPAD, device=dev, dtype=F32)          # persistent: re-draws read them again (Q5)
+        self.logits_new = torch.zeros(B, VPAD, device=dev, dtype=F32)      # this step's logits before the row select
         self.qkv = torch.zeros(B, 3 * HD, device=dev, dtype=BF16)
         self.vec = torch.zeros(B, HD, device=dev, dtype=BF16)
 
@@ -60,6 +65,8 @@ class DecodeState:
         m = self.model
         T0, B = ctx.shape
         assert B == self.B
+        if T0 >= self.Lmax:
+            raise CommuHipError(f"context of {T0} tokens does not fit a decode cache of {self.Lmax} positions")
         _, _, qkvs = m._run_forward(ctx, None, None, None, need_grad=False, want_logits=True, want_kv=True)
         H, DH = m.n_head, m._DHp
         for i, qkv in enumerate(qkvs):
@@ -68,43 +75,13 @@ class DecodeState:
             self.vc[i, :, :, :T0].copy_(kv[:, :, 2].permute(1, 2, 0, 3))
         self.klen.fill_(T0)
 
-    # ---- hipGraph-captured step: the ~60 launches of one decode step + the sampling kernel replayed as one
-    # graph from static input buffers (launch-bound otherwise: each kernel runs for only a few microseconds)
-    def capture(self, temperature: float, top_k: int):
-        dev = self.klen.device
-        B = self.B
-        self.g_tok = torch.zeros(B, dtype=torch.long, device=dev)
-        self.g_active = torch.ones(B, dtype=torch.uint8, device=dev)
-        self.g_keep = torch.ones(B, dtype=torch.uint8, device=dev)
-        self.g_draw = torch.ones(B, dtype=torch.uint8, device=dev)
-        self.g_uni = torch.full((B,), 0.5, device=dev)
-        self.g_wrong = torch.zeros(B, 729, dtype=torch.uint8, device=dev)
-        self.g_out = torch.zeros(B, dtype=torch.int32, device=dev)
-        klen0 = self.klen.clone()
-
-        def body():
-            self.step(self.g_tok, self.g_active, self.g_keep)
-            ops.sample_topk(self.logits, temperature, top_k, wrong=self.g_wrong, uniforms=self.g_uni,
-                            active=self.g_draw, token=self.g_out)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            body()                                   # warm-up (allocations) outside capture
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            body()
-        self.klen.copy_(klen0)                       # warm-up / capture advanced the lengths
-        return self.graph
-
     def step(self, tokens: torch.Tensor, active: Optional[torch.Tensor], keep: torch.Tensor, want_logits=True):
         """One decode step for the sequences with active[b] != 0; klen advances where keep[b] != 0.
         tokens int64 [B]; active/keep uint8 [B].  Returns the fp32 logits buffer [B, 768] (rows of inactive
-        sequences keep their previous content -- they may still be needed for a re-draw, quirk Q5)."""
+        sequences keep their previous content -- they may still be needed for a re-draw, quirk Q5).
+        No host synchronisation, no data-dependent allocation: safe inside a hipGraph capture."""
         m = self.model
-        dev = tokens.device
         B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
-        HD = H * DH
         h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight, ld=D)
         scale = m.attn_scale
         u, vb = m._uv()
@@ -125,115 +102,205 @@ class DecodeState:
             V = m.n_token
             if active is None:
                 ops.gemm_nt(h, m._emb_bf16(), out=self.logits[:, :V], bias=m.crit.out_layers[0].bias)
-            else:       # only overwrite the rows of the sequences that stepped
-                tmp = ops.gemm_nt(h, m._emb_bf16(), bias=m.crit.out_layers[0].bias,
-                                  out=torch.empty(B, 768, device=dev, dtype=F32)[:, :V])
-                self.logits[:, :V] = torch.where(active.bool()[:, None], tmp, self.logits[:, :V])
+            else:       # only the rows of the sequences that stepped are replaced
+                ops.gemm_nt(h, m._emb_bf16(), out=self.logits_new[:, :V], bias=m.crit.out_layers[0].bias)
+                call("commu_copy_rows_masked_f32", _p(self.logits), VPAD, _p(self.logits_new), VPAD, _p(active),
+                     B, V, _s())
         return self.logits
 
 
-class _Seq:
-    __slots__ = ("seq", "teacher", "first", "done", "failed", "iters")
+class ForcedDecoder:
+    """The device-resident decode loop for B sequences: state records + token buffers + one hipGraph per iteration.
+
+    load() uploads the conditioning (context tokens, chord progressions, uniform variates), run() replays the
+    iteration graph until every sequence is finished, sequences() downloads the results."""
+
+    POLL = 16          # iterations between two looks at the `done` flags (one D2H of B ints)
+
+    def __init__(self, model, B: int, generation_length: int, memory_length: int, temperature: float, top_k: int,
+                 max_chords: int = 64, record_trace: bool = False):
+        self.model, self.B = model, B
+        self.generation_length, self.temperature, self.top_k = int(generation_length), float(temperature), int(top_k)
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.NF = call("commu_forcing_state_ints")
+        self.n_ctx_max = 16
+        # a sequence grows by at most one token per iteration; its cache by at most one row per iteration
+        lmax = min(int(memory_length) + 1, DecodeState.MAX_POSITIONS)
+        if self.n_ctx_max + self.generation_length + 1 > lmax:
+            raise CommuHipError(
+                f"context + generation_length ({self.generation_length}) exceeds the decode memory of {lmax} positions; the "
+                "reference would start sliding its memory window here, which the K/V-cache step does not implement")
+        self.state = DecodeState(model, B, lmax)
+        self.ld_seq = self.n_ctx_max + self.generation_length + 2
+        self.ld_chord = max_chords
+        self.ld_u = self.generation_length + 1
+        i32, u8 = torch.int32, torch.uint8
+        self.fsm = torch.zeros(B, self.NF, dtype=i32, device=dev)
+        self.seq = torch.zeros(B, self.ld_seq, dtype=i32, device=dev)
+        self.chord_tok = torch.zeros(B, max_chords, dtype=i32, device=dev)
+        self.chord_pos = torch.zeros(B, max_chords, dtype=i32, device=dev)
+        self.wrong = torch.zeros(B, TOKEN_OFFSET.VOCAB_SIZE, dtype=u8, device=dev)
+        self.utable = torch.full((B, self.ld_u), 0.5, dtype=F32, device=dev)
+        self.tok = torch.zeros(B, dtype=torch.long, device=dev)
+        self.active = torch.zeros(B, dtype=u8, device=dev)
+        self.keep = torch.zeros(B, dtype=u8, device=dev)
+        self.draw = torch.zeros(B, dtype=u8, device=dev)
+        self.uni = torch.zeros(B, dtype=F32, device=dev)
+        self.token = torch.zeros(B, dtype=i32, device=dev)
+        self.probs = None
+        self.ld_trace = 2 * (self.generation_length + 2) if record_trace else 0
+        self.trace = torch.zeros(B, self.ld_trace, dtype=i32, device=dev) if record_trace else None
+        self.graph = None
+        self.n_cond = 0
+
+    # ---- one loop iteration as kernel launches on the current stream (captured by build_graph, or run eagerly)
+    def iteration(self, want_probs: bool = False):
+        B = self.B
+        call("commu_forcing_pre", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_tok), _p(self.chord_pos),
+             self.ld_chord, _p(self.wrong), _p(self.utable), self.ld_u, self.generation_length, _p(self.tok),
+             _p(self.active), _p(self.keep), _p(self.draw), _p(self.uni), _p(self.trace), self.ld_trace, B, _s())
+        self.state.step(self.tok, self.active, self.keep)
+        if want_probs and self.probs is None:
+            self.probs = torch.zeros(B, TOKEN_OFFSET.VOCAB_SIZE, device=self.dev)
+        ops.sample_topk(self.state.logits, self.temperature, self.top_k, wrong=self.wrong, uniforms=self.uni,
+                        active=self.draw, token=self.token, probs_out=self.probs if want_probs else None)
+        call("commu_forcing_post", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_pos), self.ld_chord,
+             _p(self.wrong), _p(self.draw), _p(self.token), None, B, _s())
+
+    def build_graph(self):
+        """Capture one iteration.  The warm-up run that the capture needs (allocator pools, lazy module state) is made
+        on a scratch copy of every buffer the iteration mutates, which is restored afterwards."""
+        st = self.state
+        # (the K/V rows the warm-up appends at klen are rewritten by the real run: the caches need no copy)
+        saved = [t.clone() for t in (self.fsm, self.seq, self.wrong, st.klen, st.logits)]
+        tr = None if self.trace is None else self.trace.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.iteration()
+        for dst, src in zip((self.fsm, self.seq, self.wrong, st.klen, st.logits), saved):
+            dst.copy_(src)
+        if tr is not None:
+            self.trace.copy_(tr)
+        return self.graph
+
+    def load(self, encoded_metas: Sequence[Sequence[int]], input_datas, uniforms: Optional[np.ndarray] = None):
+        """Conditioning of all B sequences: context [0] + meta[:n-1] into the caches (the n-th meta token is fed by
+        the first loop iteration, its memory discarded: quirk Q3), chord progressions, variates."""
+        B = self.B
+        assert len(encoded_metas) == B and len(input_datas) == B
+        n_cond = len(encoded_metas[0])
+        if n_cond + 1 > self.n_ctx_max or any(len(m) != n_cond for m in encoded_metas):
+            raise CommuHipError("encoded_meta: every sequence needs the same number (<= 15) of conditioning tokens")
+        self.n_cond = n_cond
+        ctx = torch.tensor([[0] + list(m[:n_cond - 1]) for m in encoded_metas], dtype=torch.long).t().contiguous()
+        self.state.kc.zero_()
+        self.state.vc.zero_()
+        self.state.prefill(ctx.to(self.dev))
+        fsm = np.zeros((B, self.NF), dtype=np.int32)
+        seq = np.zeros((B, self.ld_seq), dtype=np.int32)
+        ctok = np.zeros((B, self.ld_chord), dtype=np.int32)
+        cpos = np.zeros((B, self.ld_chord), dtype=np.int32)
+        self.reports: List[ForcingReport] = []
+        for b, (meta, data) in enumerate(zip(encoded_metas, input_datas)):
+            comps = data.chord_token_components
+            ct, cp = list(comps["chord_token"]), list(comps["chord_position"])
+            if len(ct) != len(cp):
+                raise AssertionError("Wrong Chord Length")                      # midi_inferrer.py:27
+            if len(ct) > self.ld_chord:
+                raise CommuHipError(f"{len(ct)} chords > max_chords={self.ld_chord}")
+            seq[b, 0] = 0
+            seq[b, 1:1 + n_cond] = meta[:n_cond]
+            ctok[b, :len(ct)], cpos[b, :len(cp)] = ct, cp
+            nm = float(data.num_measures)
+            rep = ForcingReport(len(ct), nm)
+            self.reports.append(rep)
+            # record: len, forced, redo, first, filled, done, failed, iters, nbar, nchord, cur, length_fit, ndraw, ntrace
+            fsm[b] = [1 + n_cond, -1, 0, 1, int(nm % 4 == 0), 0, 0, 0, 0, len(ct), 0, int(rep.length_fit), 0, 0]
+        self.fsm.copy_(torch.from_numpy(fsm))
+        self.seq.copy_(torch.from_numpy(seq))
+        self.chord_tok.copy_(torch.from_numpy(ctok))
+        self.chord_pos.copy_(torch.from_numpy(cpos))
+        self.wrong.zero_()
+        if self.trace is not None:
+            self.trace.zero_()
+        if uniforms is not None:
+            u = np.full((B, self.ld_u), 0.5, dtype=np.float32)
+            n = min(uniforms.shape[1], self.ld_u)
+            u[:, :n] = uniforms[:, :n]
+            self.utable.copy_(torch.from_numpy(u))
+
+    def run(self, use_graph: bool = True):
+        if use_graph and self.graph is None:
+            self.build_graph()
+        it = 0
+        while it < self.generation_length + 1:
+            for _ in range(self.POLL):
+                if use_graph:
+                    self.graph.replay()
+                else:
+                    self.iteration()
+            it += self.POLL
+            if bool(self.fsm[:, 5].all().item()):          # every record's `done` flag (the one sync per POLL steps)
+                break
+
+    def sequences(self):
+        """Token lists (None where nothing could be drawn, Q12) and, per sequence, the model-step trace
+        [(fed token, memory length before, after)] when it was recorded."""
+        fsm = self.fsm.cpu().numpy()
+        seq = self.seq.cpu().numpy()
+        out, traces = [], []
+        tr = None if self.trace is None else self.trace.cpu().numpy()
+        for b in range(self.B):
+            self.reports[b].consumed = int(fsm[b, 10])
+            out.append(None if fsm[b, 6] else seq[b, :fsm[b, 0]].tolist())
+            if tr is not None:
+                klen, t = self.n_cond, []
+                for k in range(min(int(fsm[b, 13]), self.ld_trace // 2)):
+                    t.append((int(tr[b, 2 * k]), klen, klen + 1))
+                    klen += int(tr[b, 2 * k + 1])
+                traces.append(t)
+        return out, traces
 
 
 class BatchedGenerator:
-    """Generates `len(input_datas)` sequences in parallel.  Each `input_data` needs temperature/top_k
-    shared by the batch and per-sequence `num_measures` / `chord_token_components`."""
+    """Generates `len(input_datas)` sequences in parallel (temperature / top_k shared by the batch, per-sequence
+    `num_measures` / `chord_token_components`).  Decoders (caches + captured graph) are kept per batch size."""
 
     def __init__(self, model, device, generation_length=4096, memory_length=4146):
         self.model, self.device = model, device
         self.generation_length, self.memory_length = generation_length, memory_length
-        self.uniform_sources = None      # optional list of callables, one per sequence
-        self.trace = None                # optional: per sequence list of (fed token, klen in, klen out)
+        self.uniform_sources = None      # optional list of callables, one per sequence (tests inject fixture variates)
+        self.trace = None                # set to a list to receive per-sequence model-step traces
+        self.use_graph = True
+        self._decoders = {}
+
+    def decoder(self, B, temperature, top_k, max_chords):
+        key = (B, float(temperature), int(top_k), self.trace is not None)
+        dec = self._decoders.get(key)
+        if dec is None or dec.ld_chord < max_chords:
+            dec = ForcedDecoder(self.model, B, self.generation_length, self.memory_length, temperature, top_k,
+                                max_chords=max(64, max_chords), record_trace=self.trace is not None)
+            self._decoders[key] = dec
+        return dec
 
     @torch.no_grad()
     def generate(self, encoded_metas: Sequence[Sequence[int]], input_datas, temperature: float, top_k: int):
         B = len(input_datas)
-        dev = self.device
-        state = DecodeState(self.model, B, min(self.memory_length + 1, 4224))
-        n_cond = len(encoded_metas[0])
-        ctx = torch.tensor([[0] + list(m[:n_cond - 1]) for m in encoded_metas], dtype=torch.long).t().contiguous()
-        state.prefill(ctx.to(dev))
-        seqs: List[_Seq] = []
-        for b in range(B):
-            s = _Seq()
-            s.seq = [0] + list(encoded_metas[b][:n_cond])
-            s.teacher = TeacherForceTask(input_datas[b])
-            s.first, s.done, s.failed, s.iters = True, False, False, 0
-            seqs.append(s)
-        klen_host = [n_cond] * B
-        rngs = self.uniform_sources or [np.random.RandomState(1000 + b).random_sample for b in range(B)]
-        wrong = torch.zeros(B, TOKEN_OFFSET.VOCAB_SIZE, dtype=torch.uint8)
-        for _ in range(self.generation_length):
-            tok = torch.zeros(B, dtype=torch.long)
-            active = torch.zeros(B, dtype=torch.uint8)
-            keep = torch.zeros(B, dtype=torch.uint8)
-            draw = torch.zeros(B, dtype=torch.uint8)
-            uni = torch.full((B,), 0.5)
-            any_live = False
-            for b, s in enumerate(seqs):
-                if s.done:
-                    continue
-                if s.iters >= self.generation_length or s.seq[-1] == 1:
-                    s.done = True
-                    continue
-                any_live = True
-                s.iters += 1
-                t = s.teacher
-                if t.next_tokens_forced:                              # midi_inferrer.py:247-251
-                    s.seq.append(t.next_tokens_forced.pop(0))
-                    tok[b], active[b], keep[b] = s.seq[-1], 1, 1
-                    continue
-                if t.no_sequence_appended:                            # :253-255 (re-draw, Q5)
-                    t.no_sequence_appended = False
-                elif s.first:                                         # :256-258 (memory discarded, Q3)
-                    tok[b], active[b], keep[b] = s.seq[-1], 1, 0
-                    s.first = False
-                else:                                                 # :259-260 (Q4)
-                    tok[b], active[b], keep[b] = s.seq[-1], 1, 1
-                if not t.incomplete_filled:
-                    t.incomplete_filled = s.seq.count(TOKEN_OFFSET.BAR) > 1
-                if t.check_first_position(s.seq):
-                    t.teach_first_position()
-                    continue
-                if t.check_one_chord_per_bar_case(s.seq) or t.check_mul_chord_per_bar_case(s.seq):
-                    t.teach_chord_token()
-                    continue
-                draw[b] = 1
-                if temperature != 0:
-                    uni[b] = float(rngs[b]())
-                wrong[b].zero_()
-                if t.wrong_tokens:
-                    wrong[b, list(t.wrong_tokens)] = 1
-            if not any_live:
-                break
-            if self.trace is not None:
-                for b in range(B):
-                    if active[b]:
-                        self.trace[b].append((int(tok[b]), klen_host[b], klen_host[b] + 1))
-                        klen_host[b] += int(keep[b])
-            if bool(active.any()):
-                state.step(tok.to(dev), active.to(dev), keep.to(dev))
-            if not bool(draw.any()):
-                continue
-            tokens = ops.sample_topk(state.logits, temperature, top_k, wrong=wrong.to(dev), uniforms=uni.to(dev),
-                                     active=draw.to(dev)).cpu()          # the one sync of this iteration
-            for b, s in enumerate(seqs):
-                if not draw[b]:
-                    continue
-                token = int(tokens[b])
-                t = s.teacher
-                if token < 0:                                         # :286-291 sampling error -> sequence dropped
-                    s.failed, s.done = True, True
-                    continue
-                if t.check_chord_position_passed(token):
-                    t.teach_chord_position()
-                elif t.check_wrong_chord_token_generated(token):
-                    t.teach_wrong_chord_token(token)
-                elif t.check_wrong_eos_generated(token):
-                    t.teach_remnant_chord()
-                elif t.check_wrong_bar_token_generated(token):
-                    t.teach_eos()
-                else:
-                    s.seq.append(token)
-        return [None if s.failed else s.seq for s in seqs], [s.teacher for s in seqs]
+        max_chords = max(len(d.chord_token_components["chord_token"]) for d in input_datas)
+        dec = self.decoder(B, temperature, top_k, max_chords)
+        uniforms = None
+        if temperature != 0:
+            srcs = self.uniform_sources or [np.random.RandomState(1000 + b).random_sample for b in range(B)]
+            uniforms = np.array([[float(srcs[b]()) for _ in range(dec.ld_u)] for b in range(B)], dtype=np.float32)
+        dec.load(encoded_metas, input_datas, uniforms)
+        dec.run(use_graph=self.use_graph)
+        seqs, traces = dec.sequences()
+        if self.trace is not None:
+            self.trace[:] = traces
+        return seqs, dec.reports

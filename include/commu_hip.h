@@ -242,6 +242,27 @@ int commu_decode_attn(const void* qkv, int ld_qkv, void* kcache, void* vcache, c
 /* klen[b] += advance[b]  (a step whose memory the reference discards does not advance: quirk Q3) */
 int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lmax, hipStream_t stream);
 
+/* ---- device-resident chord / bar forcing of the decode loop (InferenceTask.generate_sequence +
+ * TeacherForceTask, commu/midi_generator/midi_inferrer.py:239-320, :16-144): per-sequence state records of
+ * commu_forcing_state_ints() int32 each, fields in this order:
+ *   len, forced (-1: none), redo, first, filled, done, failed, iters, nbar, nchord, cur, length_fit, ndraw, ntrace.
+ * seq: int32 [B][ld_seq] token buffers; chord_tok / chord_pos: int32 [B][ld_chord] (the progression to force);
+ * wrong: uint8 [B][729] rejected-chord bitmap; utable: fp32 [B][ld_u] uniform variates, one per draw.
+ * commu_forcing_pre decides this iteration's model step and draw: tok (int64 [B]: token fed), active (step?),
+ * keep (does the step's memory stay? quirk Q3), draw (is a token drawn?), uni (its variate); trace (optional,
+ * int32 [B][ld_trace]) records (token, keep) of every model step.  commu_forcing_post applies the drawn token
+ * (token[b] < 0: nothing could be drawn, Q12).  live (optional): += number of unfinished sequences. */
+int commu_forcing_state_ints(void);
+int commu_forcing_pre(int* state, int* seq, int ld_seq, const int* chord_tok, const int* chord_pos, int ld_chord,
+                      unsigned char* wrong, const float* utable, int ld_u, int max_iters, long long* tok,
+                      unsigned char* active, unsigned char* keep, unsigned char* draw, float* uni, int* trace,
+                      int ld_trace, int B, hipStream_t stream);
+int commu_forcing_post(int* state, int* seq, int ld_seq, const int* chord_pos, int ld_chord, unsigned char* wrong,
+                       const unsigned char* draw, const int* token, int* live, int B, hipStream_t stream);
+/* dst[b][0:n] = src[b][0:n] where mask[b] != 0 */
+int commu_copy_rows_masked_f32(float* dst, int ldd, const float* src, int lds, const unsigned char* mask, int rows,
+                               int n, hipStream_t stream);
+
 /* library identification */
 const char* commu_hip_version(void);
 

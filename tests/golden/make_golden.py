@@ -325,7 +325,11 @@ def g6():
         ("sample4x", 0.95, 4, [199, 285, 267, 258, 199, 285], [432, 496, 432, 432, 496, 432], 400, 9,
          sample_bias),
         ("greedy5", 0.0, 5, [199, 285, 267, 258], [432] * 4, 200, None, greedy_bias),
+        # sampled, every variate at least MARGIN away from every step of the CDF it is drawn from: reduced-precision
+        # logits cannot flip a draw, so this trace must be reproduced token for token
+        ("sample8m", 0.95, 8, list(CHORD_TOKEN), list(CHORD_POSITION), 400, 11, sample_bias),
     ]
+    MARGIN = 0.04
     for tag, temp, nm, ctok, cpos, glen, useed, bias in cases:
         calls.clear()
         final.clear()
@@ -337,16 +341,28 @@ def g6():
         task = mi.InferenceTask(torch.device("cpu"))
         task(model=model, input_data=input_data,
              inference_cfg=ns(GENERATION=ns(generation_length=glen)))
-        uniforms = []
+        uniforms, draw_tokens, draw_margin = [], [], []
         if useed is not None:
             rng = np.random.RandomState(useed)
+            want_margin = MARGIN if tag.endswith("m") else 0.0
 
-            def infer(self, probs, rng=rng, uniforms=uniforms):
-                u = float(rng.uniform(0.02, 0.98))
-                uniforms.append(u)
+            def infer(self, probs, rng=rng, uniforms=uniforms, want_margin=want_margin):
                 cdf = torch.cumsum(probs.double(), 0)
+                best = None
+                for _ in range(400):
+                    u = float(rng.uniform(0.02, 0.98))
+                    margin = float((cdf - u).abs().min())
+                    if best is None or margin > best[1]:
+                        best = (u, margin)
+                    if margin >= want_margin:
+                        break
+                u, margin = best
+                uniforms.append(u)
                 t = int(torch.searchsorted(cdf, torch.tensor(u, dtype=torch.float64), right=True))
-                return min(t, probs.numel() - 1)
+                t = min(t, probs.numel() - 1)
+                draw_tokens.append(t)
+                draw_margin.append(margin)
+                return t
             mi.InferenceTask.infer_token = infer
         with torch.no_grad():
             seq, mems = task.init_seq_and_mems(list(ENCODED_META), len(ENCODED_META))
@@ -355,6 +371,8 @@ def g6():
         out[f"{tag}_chord_token"] = np.array(ctok)
         out[f"{tag}_chord_position"] = np.array(cpos)
         out[f"{tag}_uniforms"] = np.array(uniforms, dtype=np.float64)
+        out[f"{tag}_draw_tokens"] = np.array(draw_tokens, dtype=np.int64)          # token of every draw, rejected ones too
+        out[f"{tag}_draw_margin"] = np.array(draw_margin, dtype=np.float64)        # |cdf - u| to the nearest CDF step
         out[f"{tag}_seq"] = np.array(final["seq"])
         out[f"{tag}_remnant"] = np.array(final["remnant"])
         out[f"{tag}_trace"] = np.array([[c[0][-1], c[1], c[2]] for c in calls[1:]])

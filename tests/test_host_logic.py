@@ -174,3 +174,27 @@ def test_meta_readme_example(golden_dir):
     assert enc == z["encoded_meta"].tolist()
     comp = t.input_data.chord_token_components
     assert comp["chord_token"] == z["chord_token"].tolist() and comp["chord_position"] == z["chord_position"].tolist()
+
+
+def test_note_validator_matches_reference_scan():
+    """validate_generated_sequence (midi_inferrer.py:322-336): a note = POSITION, VELOCITY, PITCH, DURATION in a row
+    (the scan visits every index that still has two successors); ForcingReport restates the structural check of
+    validate_teacher_forced_sequence (:146-169)."""
+    from commu_amd.midi_generator.midi_inferrer import ForcingReport, count_notes
+    note = [440, 150, 60, 320]
+    assert count_notes([0, 2] + note + [1]) == 1
+    assert count_notes([0, 2] + note) == 1
+    assert count_notes([0, 2, 440, 150, 60]) == 0            # no duration token
+    assert count_notes([0, 2, 440, 150, 60, 2, 1]) == 0
+    assert count_notes([0] + note + note + [1]) == 2
+    rep = ForcingReport(4, 4.0)
+    assert rep.length_fit
+    seq = [0] + [2, 432, 199] * 4 + [1]
+    rep.consumed = 4
+    rep.validate_teacher_forced_sequence(seq)
+    rep.consumed = 3
+    with pytest.raises(Exception, match="remnant chord"):
+        rep.validate_teacher_forced_sequence(seq)
+    rep.consumed = 4
+    with pytest.raises(Exception, match="bar length"):
+        rep.validate_teacher_forced_sequence(seq[:-4] + [1])
