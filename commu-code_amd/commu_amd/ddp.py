@@ -57,15 +57,31 @@ class GradReducer:
 
     # ---- overlapped exchange (one optimiser step): begin -> range_ready* -> finish
     def begin(self):
-        self._handles, self._fired, self._pending = [], [], None
+        self._handles, self._fired, self._pending, self._events = [], [], None, []
 
     def _fire(self, flat_g, a, b):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        events, self._events = self._events, []
+        if events and flat_g.is_cuda:
+            if self._avg:
+                # RCCL orders a collective after the stream it is launched from: launch from a stream that waits for the
+                # producers' events, so that neither the main nor the weight-gradient stream is held up
+                if self._stream is None:
+                    self._stream = torch.cuda.Stream(device=flat_g.device)
+                with torch.cuda.stream(self._stream):
+                    for ev in events:
+                        self._stream.wait_event(ev)
+                    self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+                self._fired.append((a, b))
+                return
+            for ev in events:               # gloo stages device tensors through the host: the data must be there
+                ev.synchronize()
         self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
         self._fired.append((a, b))
 
-    def range_ready(self, flat_g, lo, hi):
-        """model.grad_ready_hook: flat_g[lo:hi] is final.  Ranges arrive top layer first (descending)."""
+    def range_ready(self, flat_g, lo, hi, events=None):
+        """model.grad_ready_hook: flat_g[lo:hi] is final once `events` (one per producing stream; None: now) have
+        completed.  Ranges arrive top layer first (descending)."""
         if self.world == 1:
             return
         if self._pending is not None and self._pending[0] == hi:
@@ -74,9 +90,12 @@ class GradReducer:
             if self._pending is not None:
                 self._fire(flat_g, *self._pending)
             self._pending = (lo, hi)
+        if events:
+            self._events.extend(events)
         if self._pending[1] - self._pending[0] >= self.bucket_elems:
             self._fire(flat_g, *self._pending)
             self._pending = None
+    range_ready.wants_events = True
 
     def finish(self, flat_g):
         if self.world == 1:
@@ -94,6 +113,18 @@ class GradReducer:
         if not self._avg:
             flat_g.mul_(1.0 / self.world)
         self._handles = []
+
+    # ---- scalar reductions of the training loop (train.py:172-174, 209-210, 264-265): ONE packed all-reduce each
+    def sum_scalars(self, values, device=None):
+        """Sum of each entry of `values` (python numbers or 0-d tensors) over the ranks, as python floats."""
+        t = torch.stack([torch.as_tensor(v, dtype=torch.float64, device=device).reshape(()) for v in values])
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [float(x) for x in t.cpu()]
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
 
     def allreduce_mean(self, model):
         fl = model._ensure_flat()

@@ -684,11 +684,22 @@ class MemTransformerLM(nn.Module):
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
             hook = getattr(self, "grad_ready_hook", None)
             if hook is not None and direct:
-                join()
-                # every gradient of layer i is final (and enqueued): its slice of the flat buffer may be exchanged
+                # every gradient of layer i is final once what has been enqueued so far on BOTH streams has run: its
+                # slice of the flat buffer may be exchanged.  The main stream is NOT joined with the side stream
+                # here (that would serialise exactly the work the side stream hides); a hook that can order itself
+                # after events (`wants_events`) gets one per stream, others get the old blocking join.
                 lo = gname[pre + "dec_attn.qkv_net.weight"]
                 hi = gname[f"layers.{i + 1}.dec_attn.qkv_net.weight"] if i + 1 < L else gname["crit.out_layers.0.bias"]
-                hook(G, lo, hi)
+                if getattr(hook, "wants_events", False):
+                    evs = [torch.cuda.Event()]
+                    evs[0].record(main)
+                    if side is not None:
+                        evs.append(torch.cuda.Event())
+                        evs[1].record(side)
+                    hook(G, lo, hi, evs)
+                else:
+                    join()
+                    hook(G, lo, hi)
         join()                     # (gE also receives the output-layer weight gradient from the side stream)
         ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0))
         if pad:

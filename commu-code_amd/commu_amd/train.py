@@ -75,6 +75,7 @@ class Trainer:
         self.log_train_loss = torch.zeros((), device=dev)
         self.log_grad_norm = torch.zeros((), device=dev)
         self.log_token_num = 0
+        self._log_step0 = 0
 
     def step(self, data, target, reset_mems, batch_token_num):
         """train.py:131-169 for one batch; returns the summed micro-batch loss (device tensor)."""
@@ -101,6 +102,9 @@ class Trainer:
             finally:
                 model.grad_ready_hook = None
             total = loss.detach() if total is None else total + loss.detach()
+            # train.py:150-154: the logging window accumulates the SUM of the micro-batch's token NLLs
+            # (mean / chunk * count * chunk), kept on the device -- the reference syncs here with .item()
+            self.log_train_loss += loss.detach() * (t != self.pad_id).sum() * chunk
         if self.reducer is not None:
             if overlap:
                 self.reducer.finish(model._ensure_flat()["g"])
@@ -111,10 +115,35 @@ class Trainer:
         self.optimizer.zero_grad()
         self.train_step += 1
         self.scheduler.step()
-        self.log_train_loss += total
         self.log_grad_norm += grad_norm
         self.log_token_num += int(batch_token_num)
         return total
+
+    def _sum_over_ranks(self, values):
+        """One packed all-reduce for a set of scalars (the reference issues one collective per scalar)."""
+        dev = next(self.model.parameters()).device
+        if self.reducer is not None:
+            return self.reducer.sum_scalars(values, device=dev)
+        return [float(torch.as_tensor(v)) for v in values]
+
+    def log_window(self):
+        """train.py:171-197: close the logging window -- ONE all-reduce of (NLL sum, grad-norm sum, token count)
+        instead of three; returns (nll per token, mean grad norm, tokens of all ranks) and resets the window."""
+        loss_sum, gnorm_sum, tokens = self._sum_over_ranks([self.log_train_loss, self.log_grad_norm, self.log_token_num])
+        steps = max(self.train_step - self._log_step0, 1)
+        self.log_train_loss.zero_()
+        self.log_grad_norm.zero_()
+        self.log_token_num = 0
+        self._log_step0 = self.train_step
+        nll = loss_sum / max(tokens, 1.0)
+        return nll, gnorm_sum / (steps * self.num_gpus), tokens
+
+    def evaluate_reduced(self, eval_iter):
+        """evaluate() + the token-count / NLL all-reduce of train.py:209-210,264-265 (one packed collective);
+        returns (tokens of all ranks, NLL per token)."""
+        tok, nll = self.evaluate(eval_iter)
+        tok_all, nll_all = self._sum_over_ranks([tok, nll / 10000.0])
+        return int(tok_all), nll_all / (max(tok_all, 1.0) / 10000.0)
 
     @torch.no_grad()
     def evaluate(self, eval_iter):
@@ -146,10 +175,35 @@ def save_checkpoint(path, model, optimizer, vocab, train_step, best_val_loss, sc
                 "best_val_loss": best_val_loss, "vocab": vocab, "amp": None}, path)
 
 
+class _ReferencePickle:
+    """pickle-module stand-in for torch.load: a checkpoint written by the reference's train.py (:39-48) pickles its
+    `vocab` object as `commu.model.dataset.BaseVocab`; that package is not needed to read the file -- class lookups
+    under `commu.` fall back to this package's restatements."""
+    import pickle as _pickle
+    __name__ = "pickle"
+    load = staticmethod(_pickle.load)
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                if module == "commu.model.dataset" and name == "BaseVocab":
+                    from .model.dataset import BaseVocab
+                    return BaseVocab
+                raise
+
+
+def read_checkpoint(path, map_location="cpu"):
+    """The checkpoint dictionary of train.py:39-48 ({model, optimizer, train_step, scheduler, best_val_loss, vocab,
+    amp}), whether this package or the reference wrote it."""
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_ReferencePickle)
+
+
 def load_checkpoint(path, model, optimizer=None, scheduler=None):
     """Resume from a checkpoint written by save_checkpoint or by the reference (train.py:493-495 reads
     checkpoint["model"]).  Returns (train_step, best_val_loss)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    ck = read_checkpoint(path)
     model.load_state_dict(ck["model"])
     if optimizer is not None and ck.get("optimizer") is not None:
         optimizer.load_state_dict(ck["optimizer"])

@@ -441,6 +441,78 @@ def g8_optim():
     save("g8_optim.npz", **out)
 
 
+def g10():
+    """A checkpoint exactly as the reference writes it (train.py:39-48: unwrapped state_dict, torch.optim.Adam state,
+    LambdaLR state, the reference's own BaseVocab instance, amp None) after two optimiser steps, plus what the
+    reference computes FROM it: generation logits of the model that model_initializer.py:36-51 builds from the file,
+    the parameters after one more optimiser step resumed from its optimiser state, and per-tensor statistics of
+    weights_init (train.py:291-342) on a wider model."""
+    import torch.optim as optim
+    from commu.model.dataset import BaseVocab as RefVocab
+    L, H, D, DI, T, B, mem_len = 2, 2, 32, 64, 10, 4, 12
+    cfg = make_cfg(L, H, D, DI, T, mem_len, False)
+    model = build_model(cfg, 41, std=0.08)
+    model.train()
+    lr = 0.004
+    opt = optim.Adam(model.parameters(), lr=lr, weight_decay=0.0)
+    env = {"cfg": ns(TRAIN=ns(warmup_step=2, lr=lr, lr_min=0.0001))}
+    ref_train_py_snippet(448, 460, env)
+    sched = optim.lr_scheduler.LambdaLR(opt, lr_lambda=env["lr_lambda"])
+    g = torch.Generator().manual_seed(12)
+
+    def step(mems):
+        data = torch.randint(1, 729, (T, B), generator=g)
+        target = torch.randint(1, 729, (T, B), generator=g)
+        model.zero_grad()
+        loss, mems = model(data, target, torch.zeros(B, dtype=torch.bool), mems)      # train.py:139-155 (one chunk)
+        loss[target != 0].float().mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)                       # :159-161
+        opt.step()                                                                    # :164
+        sched.step()                                                                  # :169
+        return data, target, mems
+    mems = None
+    for _ in range(3):
+        _, _, mems = step(mems)
+    checkpoint = {"model": model.state_dict(), "optimizer": opt.state_dict(), "train_step": 3,
+                  "scheduler": sched.state_dict(), "best_val_loss": 6.25, "vocab": RefVocab()}
+    checkpoint["amp"] = None
+    path = os.path.join(HERE, "g10_checkpoint.pt")
+    torch.save(checkpoint, path)
+    print(f"wrote g10_checkpoint.pt: {os.path.getsize(path) / 1024:.0f} KiB")
+    out = {"meta": np.array([L, H, D, DI, T, B, mem_len])}
+    # --- what model_initializer.py:36-51 does with the file (same_length=True, strict=False, eval, reset_length)
+    gen_cfg = make_cfg(L, H, D, DI, T, mem_len, True)
+    gm = MemTransformerLM(gen_cfg, Vocab())
+    gm.load_state_dict(torch.load(path, weights_only=False)["model"], strict=False)
+    gm.eval()
+    gm.reset_length(1, 4146)
+    ctx = torch.tensor([0] + ENCODED_META[:10])[:, None]
+    with torch.no_grad():
+        lg, gmems = gm.forward_generate(ctx, None)
+        out["gen_ctx"] = ctx.numpy()
+        out["gen_logits0"] = lg.numpy()
+        toks = [ENCODED_META[10], 2, 432]
+        for i, t in enumerate(toks):
+            lg, gmems = gm.forward_generate(torch.tensor([[t]]), gmems)
+            out[f"gen_logits{i + 1}"] = lg.numpy()
+        out["gen_tokens"] = np.array(toks)
+    # --- resume: one more optimiser step from the saved optimiser / scheduler state (no memory carried over)
+    data, target, _ = step(None)
+    out["resume_data"], out["resume_target"] = data.numpy(), target.numpy()
+    out["resume_lr"] = np.array(opt.param_groups[0]["lr"])
+    for k, v in model.state_dict().items():
+        if k != "crit.out_layers.0.weight":
+            out["after::" + k] = v.detach().numpy().copy()
+    # --- weights_init statistics (reference init on a model wide enough for stable moments)
+    wcfg = make_cfg(2, 4, 256, 512, 16, 16, False)
+    wm = build_model(wcfg, 5)
+    for k, v in wm.state_dict().items():
+        if k in ("crit.out_layers.0.weight", "pos_emb.inv_freq"):
+            continue
+        out["init::" + k] = np.array([float(v.mean()), float(v.std()) if v.numel() > 1 else 0.0, float(v.abs().max())])
+    save("g10_checkpoint.npz", **out)
+
+
 def g8_dataset():
     from commu.model.dataset import ComMUDataset
     rng = np.random.RandomState(4)
@@ -612,7 +684,7 @@ def g7_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g7c", "g8o", "g8d", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7", "g7c", "g8o", "g8d", "g9", "g10"]
     if "g1" in which:
         g1("mem", 2, 2, 64, 128, 12, 3, 16, False)
         g1("nomem", 2, 2, 64, 128, 12, 3, 0, False)
@@ -625,6 +697,8 @@ if __name__ == "__main__":
         g45()
     if "g6" in which:
         g6()
+    if "g10" in which:
+        g10()
     if "g7" in which:
         g7()
     if "g7c" in which:

@@ -198,3 +198,61 @@ def test_note_validator_matches_reference_scan():
     rep.consumed = 4
     with pytest.raises(Exception, match="bar length"):
         rep.validate_teacher_forced_sequence(seq[:-4] + [1])
+
+
+@pytest.mark.parametrize("seed,nseq,B,T", [(0, 23, 4, 8), (1, 9, 8, 5), (2, 60, 7, 16), (3, 12, 3, 4)])
+def test_epoch_scheduler_matches_the_reference_loop_over_epochs(seed, nseq, B, T):
+    """The list-scheduling epoch planner + vectorised gather against the oracle's restatement of the reference's
+    per-column / per-batch loop (dataset.py:117-183): ragged corpora with one-token sequences, columns that run dry,
+    three shuffled epochs and the single unshuffled pass."""
+    from oracle.dataset_ref import packed_batches
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(0, 4 * T, size=nseq)
+    lens[rng.randint(0, nseq, size=3)] = 0                     # sequences that are only the start token
+    raw = [rng.randint(1, 729, size=n) for n in lens]
+    ds = ComMUDataset(None, None, sequences={"train": raw, "valid": raw})
+    seqs = [np.insert(a.astype(np.int64), 0, 0) for a in raw]
+    for shuffle in (True, False):
+        want = list(packed_batches(seqs, B, T, shuffle, 77 if shuffle else None, max_batches=10 ** 6 if not shuffle else 0))
+        if shuffle:
+            per_epoch = sum(1 for _ in packed_batches(seqs, B, T, False, None, 10 ** 6))
+            want = list(packed_batches(seqs, B, T, True, 77, max_batches=3 * per_epoch + 2))
+        it = ds.get_iterator(B, T, "cpu", "train", shuffle, seed=77 if shuffle else None)()
+        got = [next(it) for _ in range(len(want))] if shuffle else list(it)
+        assert len(got) == len(want)
+        for i, ((d, t, r, n), (wd, wt, wr, wn)) in enumerate(zip(got, want)):
+            assert np.array_equal(d.numpy(), wd) and np.array_equal(t.numpy(), wt), (shuffle, i)
+            assert np.array_equal(r.numpy(), wr) and n == wn, (shuffle, i)
+
+
+def test_weights_init_matches_reference_statistics(golden_dir):
+    """weights_init (train.py:291-342) as restated in commu_amd.train: per-tensor moments against the ones the
+    reference's own function produced on the same shape (g10 fixture): N(0, 0.01) Linear / Embedding weights and
+    r_*_bias, zero biases, N(1, 0.01) LayerNorm weights."""
+    from commu_amd.train import build_model
+    z = load(golden_dir, "g10_checkpoint.npz")
+    cfg = get_cfg(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=16, mem_length=16)
+    model = build_model(cfg, BaseVocab(), "cpu", seed=3)
+    sd = model.state_dict()
+    keys = [k[6:] for k in z.files if k.startswith("init::")]
+    assert set(keys) == {k for k in sd if k not in ("crit.out_layers.0.weight", "pos_emb.inv_freq")}
+    for k in keys:
+        mean_ref, std_ref, amax_ref = z["init::" + k]
+        v = sd[k].float()
+        if amax_ref == 0:                                   # biases
+            assert float(v.abs().max()) == 0, k
+            continue
+        n = v.numel()
+        assert abs(float(v.mean()) - mean_ref) < 6 * std_ref / np.sqrt(n) + 1e-6, k
+        assert abs(float(v.std()) / std_ref - 1) < 0.25, k
+    assert abs(float(sd["layers.0.pos_ff.layer_norm.weight"].mean()) - 1.0) < 5e-3
+
+
+def test_reference_written_checkpoint_is_readable_without_the_reference(golden_dir):
+    """train.py:39-48 layout incl. the pickled `commu.model.dataset.BaseVocab` instance."""
+    from commu_amd.train import read_checkpoint
+    ck = read_checkpoint(os.path.join(golden_dir, "g10_checkpoint.pt"))
+    assert sorted(ck) == ["amp", "best_val_loss", "model", "optimizer", "scheduler", "train_step", "vocab"]
+    assert isinstance(ck["vocab"], BaseVocab) and len(ck["vocab"]) == 729 and ck["amp"] is None
+    assert ck["train_step"] == 3 and "layers.1.dec_attn.r_net.weight" in ck["model"]
+    assert set(ck["optimizer"]["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}

@@ -291,3 +291,141 @@ def test_all_pad_targets_and_input_check(golden_dir):
     bad[0, 0] = 729
     with pytest.raises(IndexError):
         model(bad, target, torch.zeros(data.shape[1], dtype=torch.bool, device=DEV), None)
+
+
+def _g10_cfg(z, same_length):
+    from commu_amd.model.config_helper import get_cfg
+    L, H, D, DI, T, B, mem_len = [int(x) for x in z["meta"]]
+    return get_cfg(num_layers=L, num_heads=H, units=D, inner_size=DI, tgt_length=T, mem_length=mem_len, batch_size=B,
+                   batch_chunk=1, dropout=0.0, attention_dropout=0.0, same_length=same_length, warmup_step=2,
+                   lr=0.004, clip=1.0)
+
+
+def test_model_initializer_on_a_reference_written_checkpoint(golden_dir):
+    """model_initializer.py:36-51 on a file the reference's train.py wrote: strict=False load, same_length,
+    eval, reset_length(1, 4146); generation logits against what the reference computes from the same file."""
+    import types
+    from commu_amd.midi_generator.model_initializer import ModelInitializeTask
+    z = load(golden_dir, "g10_checkpoint.npz")
+    task = ModelInitializeTask(types.SimpleNamespace(checkpoint_dir=os.path.join(golden_dir, "g10_checkpoint.pt")),
+                               map_location="cpu", device=torch.device(DEV), training_cfg=_g10_cfg(z, False))
+    model = task.execute()
+    assert model.same_length and not model.training and (model.tgt_len, model.mem_len) == (1, 4146)
+    with torch.no_grad():
+        logits, mems = model.forward_generate(torch.from_numpy(z["gen_ctx"]).to(DEV), None)
+        assert relerr(logits, z["gen_logits0"]) < 3e-2
+        for i, t in enumerate(z["gen_tokens"].tolist()):
+            logits, mems = model.forward_generate(torch.tensor([[t]], device=DEV), mems)
+            assert relerr(logits, z[f"gen_logits{i + 1}"]) < 3e-2, i
+        assert mems.shape[1] == z["gen_ctx"].shape[0] + 3
+
+
+def test_training_resumes_from_the_reference_optimizer_state(golden_dir):
+    """Adam moments / step counts and the LambdaLR position written by the reference (torch.optim.Adam's state_dict)
+    are taken over by FusedAdam: one more optimiser step moves every tensor the way the reference's next step does."""
+    from commu_amd.model.dataset import BaseVocab
+    from commu_amd.model.model import MemTransformerLM
+    from commu_amd.train import Trainer, read_checkpoint
+    z = load(golden_dir, "g10_checkpoint.npz")
+    ck = read_checkpoint(os.path.join(golden_dir, "g10_checkpoint.pt"))
+    cfg = _g10_cfg(z, False)
+    model = MemTransformerLM(cfg, BaseVocab())
+    model.load_state_dict(ck["model"])
+    model = model.to(DEV).train()
+    trainer = Trainer(model, cfg)
+    trainer.optimizer.load_state_dict(ck["optimizer"])
+    trainer.scheduler.load_state_dict(ck["scheduler"])
+    assert abs(trainer.optimizer.param_groups[0]["lr"] - ck["scheduler"]["_last_lr"][0]) < 1e-12
+    data, target = torch.from_numpy(z["resume_data"]).to(DEV), torch.from_numpy(z["resume_target"]).to(DEV)
+    trainer.step(data, target, torch.zeros(data.shape[1], dtype=torch.bool, device=DEV), int((z["resume_target"] != 0).sum()))
+    assert abs(trainer.optimizer.param_groups[0]["lr"] - float(z["resume_lr"])) < 1e-9
+    ups, refs = [], []
+    for name, p in model.named_parameters():
+        before = ck["model"][name].float()
+        ups.append((p.detach().cpu() - before).flatten())
+        refs.append((torch.from_numpy(z["after::" + name]) - before).flatten())
+    u, r = torch.cat(ups), torch.cat(refs)
+    cos = float(torch.dot(u, r) / (u.norm() * r.norm()))
+    assert cos > 0.97 and abs(float(u.norm() / r.norm()) - 1) < 0.05, (cos, float(u.norm() / r.norm()))
+
+
+def _write_output_npy(dirname, seqs):
+    """The reference's on-disk corpus (preprocessor.py:161-162 / dataset.py:74-87): object arrays of 11 meta ints
+    and int16 event arrays."""
+    for split, tag in (("train", "train"), ("valid", "val")):
+        metas = np.array([np.array(s[:11], dtype=object) for s in seqs[split]], dtype=object)
+        ev = np.empty(len(seqs[split]), dtype=object)
+        for i, s in enumerate(seqs[split]):
+            ev[i] = np.asarray(s[11:]).astype(np.int16)
+        np.save(os.path.join(dirname, f"input_{tag}.npy"), metas, allow_pickle=True)
+        np.save(os.path.join(dirname, f"target_{tag}.npy"), ev, allow_pickle=True)
+
+
+def _load_script(name):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("commu_cli_" + name, os.path.join(root, "commu-code_amd", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_train_cli_runs_on_an_output_npy_directory(tmp_path):
+    """BASELINE.json configs[0] plumbing: the reference's `train.py --data_dir --work_dir` flags on a synthetic corpus
+    in the on-disk format: steps, logging windows, evaluation, checkpoint_last / checkpoint_best (train.py:113-288)."""
+    from commu_amd.train import read_checkpoint
+    rng = np.random.RandomState(0)
+    corpus = {s: [np.concatenate([rng.randint(560, 729, 11), rng.randint(2, 560, rng.randint(20, 90)), [1]])
+                  for _ in range(n)] for s, n in (("train", 40), ("valid", 12))}
+    data_dir, work = tmp_path / "output_npy", tmp_path / "work"
+    data_dir.mkdir()
+    _write_output_npy(str(data_dir), corpus)
+    cli = _load_script("train")
+    run_dir = cli.main(["--data_dir", str(data_dir), "--work_dir", str(work), "--num_layers", "2", "--num_heads", "2",
+                        "--units", "64", "--inner_size", "128", "--tgt_length", "16", "--mem_length", "16",
+                        "--batch_size", "4", "--batch_chunk", "2", "--max_step", "6", "--log_interval", "2",
+                        "--eval_interval", "3"])
+    log = open(os.path.join(run_dir, "train_rank0.log")).read()
+    assert log.count("Train Step") == 3 and log.count("Eval step") == 2 and "End of training" in log
+    assert os.path.exists(os.path.join(run_dir, "config.yml"))
+    for name in ("checkpoint_last.pt", "checkpoint_best.pt"):
+        ck = read_checkpoint(os.path.join(run_dir, name))
+        assert ck["train_step"] in (3, 6) and ck["amp"] is None and "optimizer" in ck
+    nll = float(log.split("nll=")[1].split(",")[0])
+    assert 5.0 < nll < 7.5                                  # ~ln(729) = 6.59 at initialisation
+
+
+def test_generate_cli_from_a_reference_checkpoint(golden_dir, tmp_path):
+    """generate.py's flags end to end on the reference-written checkpoint: model initialiser, meta encoding, parallel
+    forced decoding, validators, sequences.json."""
+    import json
+    z = load(golden_dir, "g10_checkpoint.npz")
+    cli = _load_script("generate")
+    parsers = cli.parse_args()
+    prog = "-".join(["Am"] * 8 + ["G"] * 8 + ["F"] * 8 + ["E"] * 8)
+    argv = ["--checkpoint_dir", os.path.join(golden_dir, "g10_checkpoint.pt"), "--output_dir", str(tmp_path / "out"),
+            "--bpm", "70", "--audio_key", "aminor", "--time_signature", "4/4", "--pitch_range", "mid_high",
+            "--num_measures", "8", "--inst", "acoustic_piano", "--genre", "newage", "--min_velocity", "60",
+            "--max_velocity", "80", "--track_role", "main_melody", "--rhythm", "standard", "--chord_progression",
+            prog + "-" + prog, "--num_generate", "2", "--max_rounds", "1"]
+    margs, _ = parsers["model_args"].parse_known_args(argv)
+    iargs, _ = parsers["input_args"].parse_known_args(argv)
+    import types
+    import commu_amd.midi_generator.model_initializer as mi
+    # the fixture checkpoint is a 2-layer model: the initialiser is told its shape (the reference always assumes
+    # the default one); generation length shortened through the inference cfg
+    orig = mi.get_default_cfg_inference
+
+    def short_cfg():
+        c = orig()
+        c.defrost()
+        c.GENERATION.generation_length = 120
+        return c
+    mi.get_default_cfg_inference = short_cfg
+    try:
+        seqs = cli.main(margs, iargs, training_cfg=_g10_cfg(z, False))
+    finally:
+        mi.get_default_cfg_inference = orig
+    out = json.load(open(tmp_path / "out" / "sequences.json"))
+    assert out["encoded_meta"] == [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
+    assert out["sequences"] == seqs and len(seqs) <= 2          # a random model rarely passes both validators
