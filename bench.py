@@ -101,6 +101,8 @@ def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
         if graph:
             dec.build_graph()
 
+        dec.pre()
+
         def run(n):
             done = 0
             while done < n:
@@ -108,7 +110,8 @@ def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
                     if graph:
                         dec.graph.replay()
                     else:
-                        dec.iteration()
+                        dec.body()
+                        dec.pre()
                 done += dec.POLL
                 live = not bool(dec.fsm[:, 5].all().item())
             return done, live

@@ -38,6 +38,7 @@ class TnProblem(C.Structure):
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
 PROTOTYPES = {
     "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, C.c_uint, c_f, c_f, c_p],
+    "commu_gemm_nt_ln_bf16": [c_p, c_i, c_p, c_p, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p],
     "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_gemm_nt_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_i, c_i,
                                    c_i, c_p, c_i, C.c_longlong, c_i, c_i, c_i, c_i, c_p],
@@ -84,7 +85,7 @@ PROTOTYPES = {
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
     "commu_forcing_state_ints": [],
     "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
-    "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_hip_version": [],
 }

@@ -75,35 +75,47 @@ class DecodeState:
             self.vc[i, :, :, :T0].copy_(kv[:, :, 2].permute(1, 2, 0, 3))
         self.klen.fill_(T0)
 
-    def step(self, tokens: torch.Tensor, active: Optional[torch.Tensor], keep: torch.Tensor, want_logits=True):
-        """One decode step for the sequences with active[b] != 0; klen advances where keep[b] != 0.
+    def step(self, tokens: torch.Tensor, active: Optional[torch.Tensor], keep: Optional[torch.Tensor], want_logits=True):
+        """One decode step for the sequences with active[b] != 0; klen advances where keep[b] != 0 (keep = None: the
+        caller advances the lengths itself, ForcedDecoder does it in its book-keeping kernel).
         tokens int64 [B]; active/keep uint8 [B].  Returns the fp32 logits buffer [B, 768] (rows of inactive
         sequences keep their previous content -- they may still be needed for a re-draw, quirk Q5).
-        No host synchronisation, no data-dependent allocation: safe inside a hipGraph capture."""
+        No host synchronisation, no data-dependent allocation: safe inside a hipGraph capture.
+
+        Kernel chain per layer: QKV Linear -> cached attention (K/V append fused in) -> o_net Linear + residual ->
+        FFN Linear 1 -> FFN Linear 2 + residual; the two LayerNorms (model.py:352,179) run INSIDE the Linear that
+        consumes them (commu_gemm_nt_ln_bf16), which also stores the normalised rows for the next residual add."""
         m = self.model
         B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
         h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight, ld=D)
         scale = m.attn_scale
         u, vb = m._uv()
+        z2, ln2 = None, None          # pre-LayerNorm output of the previous layer's FFN and that LayerNorm
         for i in range(L):
             w = m._weights(i)
             lay = m.layers[i]
-            ops.gemm_nt(h, w["qkv"], out=self.qkv)
+            if z2 is None:
+                ops.gemm_nt(h, w["qkv"], out=self.qkv)
+            else:                     # h = LN2(z2) of the layer below, computed on the fly and stored
+                h = torch.empty_like(z2)
+                ops.gemm_nt_ln(z2, ln2.weight, ln2.bias, w["qkv"], out=self.qkv, a_out=h, eps=ln2.eps)
             call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
                  _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
                  _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, _s())      # (K/V append fused in)
             z1 = ops.gemm_nt(self.vec, w["o"], resid=h)
-            a, _, _ = ops.layernorm_fwd(z1, lay.dec_attn.layer_norm.weight, lay.dec_attn.layer_norm.bias)
-            hid = ops.gemm_nt(a, w["w1"], bias=w["b1"], relu=True)
+            ln1 = lay.dec_attn.layer_norm
+            a = torch.empty_like(z1)
+            hid = ops.gemm_nt_ln(z1, ln1.weight, ln1.bias, w["w1"], a_out=a, bias=w["b1"], relu=True, eps=ln1.eps)
             z2 = ops.gemm_nt(hid, w["w2"], bias=w["b2"], resid=a)
-            h, _, _ = ops.layernorm_fwd(z2, lay.pos_ff.layer_norm.weight, lay.pos_ff.layer_norm.bias)
-        call("commu_decode_advance", _p(self.klen), _p(keep), B, self.Lmax, _s())
+            ln2 = lay.pos_ff.layer_norm
+        if keep is not None:
+            call("commu_decode_advance", _p(self.klen), _p(keep), B, self.Lmax, _s())
         if want_logits:
             V = m.n_token
-            if active is None:
-                ops.gemm_nt(h, m._emb_bf16(), out=self.logits[:, :V], bias=m.crit.out_layers[0].bias)
-            else:       # only the rows of the sequences that stepped are replaced
-                ops.gemm_nt(h, m._emb_bf16(), out=self.logits_new[:, :V], bias=m.crit.out_layers[0].bias)
+            dst = self.logits if active is None else self.logits_new
+            ops.gemm_nt_ln(z2, ln2.weight, ln2.bias, m._emb_bf16(), out=dst[:, :V], bias=m.crit.out_layers[0].bias,
+                           eps=ln2.eps)
+            if active is not None:       # only the rows of the sequences that stepped are replaced
                 call("commu_copy_rows_masked_f32", _p(self.logits), VPAD, _p(self.logits_new), VPAD, _p(active),
                      B, V, _s())
         return self.logits
@@ -154,36 +166,49 @@ class ForcedDecoder:
         self.graph = None
         self.n_cond = 0
 
-    # ---- one loop iteration as kernel launches on the current stream (captured by build_graph, or run eagerly)
-    def iteration(self, want_probs: bool = False):
-        B = self.B
+    # ---- one loop iteration = decide (pre) -> model step -> sampling step -> book-keeping (post), as kernel launches
+    # on the current stream.  The captured graph holds [step, sample, post, pre of the NEXT iteration]: run() issues
+    # the very first `pre` on its own, so a replay is four stages and the kernel sequence is the same as eager.
+    def pre(self):
         call("commu_forcing_pre", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_tok), _p(self.chord_pos),
              self.ld_chord, _p(self.wrong), _p(self.utable), self.ld_u, self.generation_length, _p(self.tok),
-             _p(self.active), _p(self.keep), _p(self.draw), _p(self.uni), _p(self.trace), self.ld_trace, B, _s())
-        self.state.step(self.tok, self.active, self.keep)
+             _p(self.active), _p(self.keep), _p(self.draw), _p(self.uni), _p(self.trace), self.ld_trace, self.B, _s())
+
+    def body(self, want_probs: bool = False):
+        B = self.B
+        self.state.step(self.tok, self.active, None)
         if want_probs and self.probs is None:
             self.probs = torch.zeros(B, TOKEN_OFFSET.VOCAB_SIZE, device=self.dev)
         ops.sample_topk(self.state.logits, self.temperature, self.top_k, wrong=self.wrong, uniforms=self.uni,
                         active=self.draw, token=self.token, probs_out=self.probs if want_probs else None)
         call("commu_forcing_post", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_pos), self.ld_chord,
-             _p(self.wrong), _p(self.draw), _p(self.token), None, B, _s())
+             _p(self.wrong), _p(self.draw), _p(self.token), None, _p(self.state.klen), _p(self.keep), self.state.Lmax,
+             B, _s())
+
+    def iteration(self, want_probs: bool = False):
+        """One complete iteration, eagerly (tests inspect the draws between iterations)."""
+        self.pre()
+        self.body(want_probs)
 
     def build_graph(self):
-        """Capture one iteration.  The warm-up run that the capture needs (allocator pools, lazy module state) is made
+        """Capture [body, pre].  The warm-up run that the capture needs (allocator pools, lazy module state) is made
         on a scratch copy of every buffer the iteration mutates, which is restored afterwards."""
         st = self.state
         # (the K/V rows the warm-up appends at klen are rewritten by the real run: the caches need no copy)
-        saved = [t.clone() for t in (self.fsm, self.seq, self.wrong, st.klen, st.logits)]
+        bufs = (self.fsm, self.seq, self.wrong, st.klen, st.logits, self.tok, self.active, self.keep, self.draw, self.uni)
+        saved = [t.clone() for t in bufs]
         tr = None if self.trace is None else self.trace.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.iteration()
+            self.body()
+            self.pre()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.iteration()
-        for dst, src in zip((self.fsm, self.seq, self.wrong, st.klen, st.logits), saved):
+            self.body()
+            self.pre()
+        for dst, src in zip(bufs, saved):
             dst.copy_(src)
         if tr is not None:
             self.trace.copy_(tr)
@@ -238,13 +263,15 @@ class ForcedDecoder:
     def run(self, use_graph: bool = True):
         if use_graph and self.graph is None:
             self.build_graph()
+        self.pre()                                          # decision of the first iteration
         it = 0
         while it < self.generation_length + 1:
             for _ in range(self.POLL):
                 if use_graph:
                     self.graph.replay()
                 else:
-                    self.iteration()
+                    self.body()
+                    self.pre()
             it += self.POLL
             if bool(self.fsm[:, 5].all().item()):          # every record's `done` flag (the one sync per POLL steps)
                 break

@@ -120,6 +120,28 @@ def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None
     return out
 
 
+def gemm_nt_ln(z, gamma, beta, B, out=None, *, a_out=None, bias=None, resid=None, relu=False, out_f32=False, eps=1e-5):
+    """Decode-step Linear with the preceding LayerNorm fused in: out = LN(z) @ B^T (+ bias, relu, resid); `a_out`
+    (bf16, same shape as z) receives LN(z).  z: [M <= 64, K] bf16 (K % 128 == 0); LN over gamma.numel() columns."""
+    M, K = z.shape
+    N = B.shape[0]
+    assert z.dtype == BF16 and B.dtype == BF16 and B.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=z.device, dtype=F32 if out_f32 else BF16)
+    if not FUSE_DECODE_LN or M > 64 or K % 128 or K > 1024 or N < 32:
+        # shapes the fused kernel does not take (tiny test models, wide batches): the two kernels it replaces
+        a, _, _ = layernorm_fwd(z, gamma, beta, y=a_out, eps=eps)
+        return gemm_nt(a, B, out=out, bias=bias, resid=resid, relu=relu)
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RESID if resid is not None else 0) | (EPI_RELU if relu else 0)
+    if out.dtype == F32:
+        flags |= EPI_OUT_F32
+    call("commu_gemm_nt_ln_bf16", _p(z), _rowmajor2d(z, "z"), _p(gamma), _p(beta), gamma.numel(), float(eps),
+         _p(a_out), 0 if a_out is None else _rowmajor2d(a_out, "a_out"), _p(B), _rowmajor2d(B, "B"), _p(out),
+         _rowmajor2d(out, "out"), M, N, K, _p(bias), _p(resid), 0 if resid is None else _rowmajor2d(resid, "resid"),
+         flags, _s())
+    return out
+
+
 def tn_slices(M: int, N: int, K: int) -> int:
     """Number of m-slices the TN kernel wants at this shape (enough workgroups to fill the GPU)."""
     return _lib.load().commu_gemm_tn_slices(int(M), int(N), int(K))
@@ -370,6 +392,10 @@ def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
 
 
 POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prove nothing reads it
+# decode step: LayerNorm inside the consuming Linear (commu_gemm_nt_ln_bf16).  Measured on MI355X (64 sequences, L6
+# D512): 0.324 ms / step fused vs 0.293 ms with the separate LayerNorm kernel -- the two LDS reductions and the
+# normalisation arithmetic cost a latency-bound skinny GEMM more than the launch they save -- so it is OFF by default.
+FUSE_DECODE_LN = False
 NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead of commu_relattn_bwd_band
 
 

@@ -124,11 +124,15 @@ __global__ __launch_bounds__(64) void forcing_post_kernel(int* __restrict__ st, 
                                                           const int* __restrict__ chord_pos, int ld_chord,
                                                           unsigned char* __restrict__ wrong,
                                                           const unsigned char* __restrict__ draw,
-                                                          const int* __restrict__ token, int* __restrict__ live) {
+                                                          const int* __restrict__ token, int* __restrict__ live,
+                                                          int* __restrict__ klen, const unsigned char* __restrict__ keep,
+                                                          int lmax) {
     const int b = blockIdx.x, lane = threadIdx.x;
     int* s = st + (size_t)b * F_COUNT;
     int clear = 0;
     if (lane == 0) {
+        // memory length of the step that just ran: it grows unless the step's memory is discarded (quirk Q3)
+        if (klen != nullptr && keep[b] && klen[b] < lmax - 1) klen[b] += 1;
         if (draw[b]) {
             const int t = token[b];
             const int cur = s[F_CUR];
@@ -190,11 +194,11 @@ extern "C" int commu_forcing_pre(int* state, int* seq, int ld_seq, const int* ch
 }
 
 extern "C" int commu_forcing_post(int* state, int* seq, int ld_seq, const int* chord_pos, int ld_chord,
-                                  unsigned char* wrong, const unsigned char* draw, const int* token, int* live, int B,
-                                  hipStream_t stream) {
+                                  unsigned char* wrong, const unsigned char* draw, const int* token, int* live,
+                                  int* klen, const unsigned char* keep, int lmax, int B, hipStream_t stream) {
     if (B <= 0) return 0;
     COMMU_LAUNCH(forcing_post_kernel, dim3(B), dim3(64), 0, stream, state, seq, ld_seq, chord_pos, ld_chord, wrong,
-                 draw, token, live);
+                 draw, token, live, klen, keep, lmax);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -263,10 +263,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 // 32 output columns, its 4 waves split K, and every wave issues ALL its fragment loads (weights and
 // activations, straight from global memory in MFMA operand layout) before the first MFMA: one round trip.
 // Partial sums meet in LDS; epilogue bias -> ReLU -> residual.
-template <int KSTEPS, bool OUT_F32, int NWV = 4>          // KSTEPS = K / (32 NWV): 32-wide MFMA steps per wave
+// LN = true: A is the PRE-LayerNorm activation z; the kernel normalises it on the fly (a = LN(z) over the first D
+// columns, gamma / beta / eps: nn.LayerNorm at model.py:179,352) and workgroup 0 also stores a (bf16) to a_out, where the
+// next residual add reads it.  Every workgroup holds all M <= 64 rows anyway, so the row statistics cost two tiny LDS
+// reductions and the decode step loses one kernel launch and one activation round trip per LayerNorm.
+struct SkinnyLN {
+    const float* gamma;
+    const float* beta;
+    bf16* a_out;
+    int lda_out, D;
+    float eps;
+};
+
+template <int KSTEPS, bool OUT_F32, int NWV = 4, bool LN = false>          // KSTEPS = K / (32 NWV): 32-wide MFMA steps per wave
 __global__ __launch_bounds__(64 * NWV) void gemm_nt_skinny_kernel(
     const bf16* __restrict__ A, int lda, const bf16* __restrict__ B, int ldb, void* __restrict__ Cv, int ldc,
-    int M, int N, const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr, int flags) {
+    int M, int N, const float* __restrict__ bias, const bf16* __restrict__ resid, int ldr, int flags, SkinnyLN ln) {
     __shared__ float red[NWV][32][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 32;
@@ -284,7 +296,65 @@ __global__ __launch_bounds__(64 * NWV) void gemm_nt_skinny_kernel(
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) af[mi][ks] = ld_bf16x8(ap + 32 * ks);
     }
+    // (LN) gamma / beta of this wave's K range: requested together with the fragments, not after the statistics
+    float gm[LN ? KSTEPS : 1][8], bt[LN ? KSTEPS : 1][8];
+    if (LN) {
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = k0 + 32 * ks + e;
+                gm[ks][e] = kk < ln.D ? ln.gamma[kk] : 0.f;
+                bt[ks][e] = kk < ln.D ? ln.beta[kk] : 0.f;
+            }
+    }
     __builtin_amdgcn_sched_barrier(0);          // every load above is in flight before the first MFMA waits
+    if (LN) {
+        // row statistics: lane (r16, g) holds 8 KSTEPS values of rows 16 mi + r16 -> reduce over g (lanes 16 apart),
+        // then over the waves through LDS.  Two passes (mean, then centred squares), like layernorm_fwd_kernel.
+        float* st = &red[0][0][0];          // [NWV][64 rows]
+        const int D = ln.D;
+        float mu[4], rs[4];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                float v = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (k0 + 32 * ks + e < D) ? bf2f(af[mi][ks][e]) : 0.f;
+                        v += pass == 0 ? x : ((k0 + 32 * ks + e < D) ? (x - mu[mi]) * (x - mu[mi]) : 0.f);
+                    }
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (g == 0) st[w * 64 + 16 * mi + r16] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                float t = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) t += st[ww * 64 + 16 * mi + r16];
+                if (pass == 0) mu[mi] = t / (float)D;
+                else rs[mi] = rsqrtf(t / (float)D + ln.eps);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int kk = k0 + 32 * ks;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    af[mi][ks][e] = f2bf(kk + e < D ? (bf2f(af[mi][ks][e]) - mu[mi]) * rs[mi] * gm[ks][e] + bt[ks][e] : 0.f);
+                if (blockIdx.x == 0 && ln.a_out != nullptr && 16 * mi + r16 < M)
+                    st_bf16x8(ln.a_out + (size_t)(16 * mi + r16) * ln.lda_out + kk, af[mi][ks]);
+            }
+        }
+    }
     f32x4 acc[2][4];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -541,20 +611,31 @@ __global__ void reduce_slabs2d_kernel(float* __restrict__ dst, int ldd, long lon
 static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                           const float* bias, const void* resid, int ldr, const void* relu_mask, int ldm, int flags,
                           unsigned drop_seed, float drop_p, float mask_scale, int batch, GemmBatch bs,
-                          hipStream_t stream) {
+                          hipStream_t stream, const SkinnyLN* ln = nullptr) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (K <= 0 || (K % 32) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
-    if (M <= 64 && batch == 1 && bs.tri_B == 0 && (K % 128) == 0 && K <= 1024 && N >= 32 &&
-        !(flags & (COMMU_EPI_DROPOUT | COMMU_EPI_RELUMASK)) && !getenv("COMMU_GEMM_NOSKINNY")) {
+    const bool skinny = M <= 64 && batch == 1 && bs.tri_B == 0 && (K % 128) == 0 && K <= 1024 && N >= 32 &&
+                        !(flags & (COMMU_EPI_DROPOUT | COMMU_EPI_RELUMASK));
+    if (ln != nullptr && !skinny) return -22;          // the LayerNorm-fused form exists for the decode step only
+    if (skinny && (ln != nullptr || !getenv("COMMU_GEMM_NOSKINNY"))) {
         dim3 grid((N + 31) / 32);
 #define SK_LAUNCH(KS, NWV)                                                                                           \
     {                                                                                                                \
-        if (flags & COMMU_EPI_OUT_F32)                                                                               \
+        if (ln != nullptr) {                                                                                         \
+            if (flags & COMMU_EPI_OUT_F32)                                                                           \
+                COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, true, NWV, true>), grid, dim3(64 * NWV), 0, stream,          \
+                             (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr,  \
+                             flags, *ln);                                                                            \
+            else                                                                                                     \
+                COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, false, NWV, true>), grid, dim3(64 * NWV), 0, stream,         \
+                             (const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr,  \
+                             flags, *ln);                                                                            \
+        } else if (flags & COMMU_EPI_OUT_F32)                                                                        \
             COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, true, NWV>), grid, dim3(64 * NWV), 0, stream, (const bf16*)A,    \
-                         lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);              \
+                         lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags, SkinnyLN{});  \
         else                                                                                                         \
             COMMU_LAUNCH((gemm_nt_skinny_kernel<KS, false, NWV>), grid, dim3(64 * NWV), 0, stream, (const bf16*)A,   \
-                         lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags);              \
+                         lda, (const bf16*)B, ldb, C, ldc, M, N, bias, (const bf16*)resid, ldr, flags, SkinnyLN{});  \
     }
         if (K % 256 == 0 && K >= 768) {          // long contraction: 8 waves split K
             switch (K / 256) {
@@ -770,4 +851,16 @@ extern "C" int commu_gemm_tn_bf16_grouped(const commu_tn_problem* probs, int npr
     a.slabs = slabs;
     a.slab_stride = slab_stride;
     return launch_gemm8_tn(a, stream);
+}
+
+/* decode-step Linear with the preceding LayerNorm fused in: C = LN(z)[M, K] . B[N, K]^T (+ bias, relu, resid);
+ * a_out (optional) receives LN(z) as bf16 */
+extern "C" int commu_gemm_nt_ln_bf16(const void* z, int ldz, const float* gamma, const float* beta, int D, float eps,
+                                     void* a_out, int lda_out, const void* B, int ldb, void* C, int ldc, int M, int N,
+                                     int K, const float* bias, const void* resid, int ldr, int flags,
+                                     hipStream_t stream) {
+    if (D <= 0 || D > K || (a_out != nullptr && (lda_out % 8))) return -22;
+    const SkinnyLN ln{gamma, beta, (bf16*)a_out, lda_out, D, eps};
+    return launch_gemm_nt(z, ldz, B, ldb, C, ldc, M, N, K, bias, resid, ldr, nullptr, 0, flags, 0u, 0.f, 1.f, 1,
+                          GemmBatch{0, 0, 0, 0, 0, 0}, stream, &ln);
 }

@@ -95,12 +95,16 @@ __device__ __forceinline__ bf16x8 frag_tr_rm(const bf16* tile, int row0, int row
     }
     return f;
 }
+// Per-wave transposed image T[k][row] (pitch PT = 16 elements = four 8-byte slots per k): slot s of row k lives at
+// physical slot s ^ ((k >> 2) & 3).  Without it the 16 lanes of a ds_write_b64 group (k = 16c + r16, same slot) hit
+// only 8 of the 32 banks (rows 32 bytes apart: 4-way conflict, a quarter of the forward kernel's LDS cycles).
+__device__ __forceinline__ int pt_off(int k, int slot) { return k * PT + ((slot ^ ((k >> 2) & 3)) << 2); }
 // A operand (16 rows x 32 k) from a per-wave transposed image T[k][row] (pitch PT)
 __device__ __forceinline__ bf16x8 frag_tr(const bf16* img, int kbase, int r16, int g) {
     bf16x8 f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const bf16x4 v = tr_read(img + (kbase + 8 * g + 4 * h + (r16 >> 2)) * PT + 4 * (r16 & 3));
+        const bf16x4 v = tr_read(img + pt_off(kbase + 8 * g + 4 * h + (r16 >> 2), r16 & 3));
         f[4 * h + 0] = v[0]; f[4 * h + 1] = v[1]; f[4 * h + 2] = v[2]; f[4 * h + 3] = v[3];
     }
     return f;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
                 if (DROP) p = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? p * a.drop_scale : 0.f;
                 pb[reg] = f2bf(p);
             }
-            *(bf16x4*)(myP + (16 * c + r16) * PT + 4 * g) = pb;       // P^T[kv][row]: rows 4g..4g+3
+            *(bf16x4*)(myP + pt_off(16 * c + r16, g)) = pb;       // P^T[kv][row]: rows 4g..4g+3
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
                 s[c][reg] = ds;
                 db[reg] = f2bf(ds);
             }
-            *(bf16x4*)(myD + (16 * c + r16) * PT + 4 * g) = db;       // dS^T[kv][row]
+            *(bf16x4*)(myD + pt_off(16 * c + r16, g)) = db;       // dS^T[kv][row]
         }
         // un-skew: dQR[row][b] = dS[row][jj = row + 63 - b]  ->  dSk[i][d = dlo_w + b]
         const int dlo_w = i0 + M - j0 - 63 + 16 * w;

@@ -41,6 +41,13 @@ int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, 
                        int K, const float* bias, const void* resid, int ldr, const void* relu_mask,
                        int ldm, int flags, unsigned drop_seed, float drop_p, float mask_scale,
                        hipStream_t stream);
+/* Decode-step form (M <= 64 rows, K % 128 == 0, K <= 1024) with the PRECEDING LayerNorm fused in (model.py:179,352
+ * followed by the Linear of :164 / :205 / :46): C = LN(z)[:, :K] . B^T with epilogue flags BIAS, RELU, RESID, OUT_F32;
+ * LN over the first D columns of z (gamma, beta, eps; columns D..K-1 are zero padding); a_out (optional, bf16
+ * [M][lda_out]) receives LN(z), which the next residual connection adds.  Other shapes: -22. */
+int commu_gemm_nt_ln_bf16(const void* z, int ldz, const float* gamma, const float* beta, int D, float eps,
+                          void* a_out, int lda_out, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                          const float* bias, const void* resid, int ldr, int flags, hipStream_t stream);
 /* batched form: entry z uses A + z*strideA, B + z*strideB, C + z*strideC, resid + z*strideR (element
  * strides); a 64-wide tile is used when N <= 64 (per-head GEMMs).  Epilogue flags: RESID, OUT_F32.
  * Causal band (tri_B > 0): A is dS by distance, row m = i*tri_B + b is zero (or unwritten) beyond column
@@ -257,8 +264,11 @@ int commu_forcing_pre(int* state, int* seq, int ld_seq, const int* chord_tok, co
                       unsigned char* wrong, const float* utable, int ld_u, int max_iters, long long* tok,
                       unsigned char* active, unsigned char* keep, unsigned char* draw, float* uni, int* trace,
                       int ld_trace, int B, hipStream_t stream);
+/* klen / keep (optional): the cache lengths of the decode step advance here (klen[b] += keep[b], capped at lmax - 1),
+ * which saves the separate commu_decode_advance launch */
 int commu_forcing_post(int* state, int* seq, int ld_seq, const int* chord_pos, int ld_chord, unsigned char* wrong,
-                       const unsigned char* draw, const int* token, int* live, int B, hipStream_t stream);
+                       const unsigned char* draw, const int* token, int* live, int* klen, const unsigned char* keep,
+                       int lmax, int B, hipStream_t stream);
 /* dst[b][0:n] = src[b][0:n] where mask[b] != 0 */
 int commu_copy_rows_masked_f32(float* dst, int ldd, const float* src, int lds, const unsigned char* mask, int rows,
                                int n, hipStream_t stream);

@@ -81,6 +81,32 @@ def test_gemm_nt_epilogues():
     assert relerr(wide[:, 100:100 + N], ref) < BF16_TOL and float(wide[:, :100].abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,N,K,D", [(64, 1536, 512, 512), (5, 729, 512, 500), (33, 1024, 1024, 1024), (64, 96, 128, 100)])
+def test_gemm_nt_layernorm_fused_decode_form(M, N, K, D):
+    """commu_gemm_nt_ln_bf16 (LayerNorm inside the decode-step Linear) against layernorm_fwd + gemm_nt: the stored
+    LN rows and the product, incl. zero-padded model widths (D < K) and the bias / relu / residual epilogue."""
+    o = ops()
+    o.FUSE_DECODE_LN = True          # (off by default: slower than the separate LayerNorm kernel in the decode step)
+    z = bf(rnd(M, K, seed=50) * 1.7 + 0.3)
+    z[:, D:] = 0
+    gamma, beta = rnd(D, seed=51) * 0.2 + 1.0, rnd(D, seed=52) * 0.1
+    W, bias, resid = bf(rnd(N, K, seed=53) * 0.1), rnd(N, seed=54), bf(rnd(M, N, seed=55))
+    zd, Wd = z.to(DEV), W.to(DEV)
+    a_ref, _, _ = o.layernorm_fwd(zd, gamma.to(DEV), beta.to(DEV))
+    ld = (N + 7) // 8 * 8
+    for kw in (dict(), dict(bias=bias.to(DEV), relu=True), dict(bias=bias.to(DEV), resid=resid.to(DEV))):
+        ref = o.gemm_nt(a_ref, Wd, out=torch.empty(M, ld, device=DEV)[:, :N], **kw)
+        a_out = torch.full((M, K), float("nan"), device=DEV, dtype=torch.bfloat16)
+        out = o.gemm_nt_ln(zd, gamma.to(DEV), beta.to(DEV), Wd, out=torch.empty(M, ld, device=DEV)[:, :N], a_out=a_out, **kw)
+        # (row statistics are reduced in a different order: LN rows may differ by one bf16 ulp)
+        assert relerr(a_out, a_ref) < 8e-3 and float(a_out[:, D:].abs().max() if D < K else 0) == 0
+        assert relerr(out, ref) < 4e-3, kw.keys()
+    o.FUSE_DECODE_LN = False
+    xf = z.float()[:, :D]
+    want = (xf - xf.mean(1, keepdim=True)) / torch.sqrt(xf.var(1, unbiased=False, keepdim=True) + 1e-5) * gamma + beta
+    assert relerr(a_out[:, :D], want) < BF16_TOL
+
+
 # the 256 x 256 x 64 eight-phase kernel (gemm8.hip): interior tiles, M / N tails, odd K-tile counts, a persistent
 # grid smaller than the tile count (COMMU_GEMM8_GRID), every epilogue
 @pytest.mark.parametrize("grid", [0, 3])
