@@ -35,6 +35,17 @@ def fwd_flops_per_token(L, D, DI, T, M, V=729):
     return L * (6 * D * D + 4 * D * D * (M / T) + 2 * D * D + 4 * D * DI + 6 * kbar * D) + 2 * D * V
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
     """The oracle's train step (oracle/xl_ref.py, a restatement of the reference pinned by the
     golden fixtures) timed on the host cores: same shape, micro-batch 2 (CPU tokens/s is roughly
@@ -63,6 +74,7 @@ def cpu_baseline(args):
             break
     per = sum(times) / len(times)
     return {"value": round(Bc * T / per, 1), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+            "cpu": f"{cpu_model()} ({os.cpu_count()} logical cpus visible)",
             "sample": f"{len(times)} optimiser steps of the same model shape at batch {Bc} x tgt_len {T} "
                       f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step)"}
 
@@ -160,54 +172,42 @@ def decode_cpu_baseline(args, steps=64):
             "sample": f"{n} sequential batch-1 steps at memory length 1000 (fp32 PyTorch-CPU oracle)"}
 
 
+def kernel_source_hash():
+    """sha256 over the attention kernel sources: the PMC traffic numbers are only valid for the code they were
+    measured on (tests/probes/pmc_traffic.py stamps the same hash into the profile)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("relattn.hip", "common.cuh"):
+        with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json,
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json,
     produced by tests/probes/pmc_traffic.sh at the DEFAULT bench shape: FETCH_SIZE x 2 (gfx950 correction of
-    MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both in KiB -> bytes).  None when the shape differs from
-    the profiled one or the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
+    MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both in KiB -> bytes).  None when no profile matches BOTH the
+    shape and the hash of the current kernel sources (a stale number is refused, not reported)."""
+    import glob
     shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // args.batch_chunk]
-    if rec.get("shape") != shape:
+    try:
+        sha = kernel_source_hash()
+    except OSError:
         return None
-    return rec.get("bytes_per_launch", {}).get(kernel)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("shape") == shape and rec.get("source_sha256") == sha:
+            return rec.get("bytes_per_launch", {}).get(kernel)
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--layers", type=int, default=6)
-    ap.add_argument("--d-model", dest="d_model", type=int, default=512)
-    ap.add_argument("--heads", type=int, default=8)
-    ap.add_argument("--d-inner", dest="d_inner", type=int, default=1024)
-    ap.add_argument("--tgt-len", dest="tgt_len", type=int, default=1024)
-    ap.add_argument("--mem-len", dest="mem_len", type=int, default=0)
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
-    ap.add_argument("--batch-chunk", type=int, default=1)
-    ap.add_argument("--dropout", type=float, default=0.1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-decode", action="store_true")
-    ap.add_argument("--no-side-stream", action="store_true",
-                    help="weight-gradient work on the main stream (default: a side stream)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
-
+def train_bench(args, dev, world, rank, steps, warmup):
+    """W untimed + K timed optimiser steps of the shape in `args`; returns (elapsed seconds (max over ranks),
+    tokens per step per rank, per-entry-point HIP-event times) -- None on ranks other than 0."""
     from commu_amd import _lib
     from commu_amd.ddp import GradReducer
     from commu_amd.model.config_helper import get_cfg
@@ -234,17 +234,17 @@ def main():
             d, t, r, n = batches[(base + i) % len(batches)]
             trainer.step(d, t, r, n)
 
-    run(args.warmup, 0)
+    run(warmup, 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     prof_names = ["commu_relattn_bwd_kv", "commu_relattn_bwd_q", "commu_relattn_fwd", "commu_gemm_nt_bf16",
-                  "commu_gemm_tn_bf16"]
+                  "commu_gemm_tn_bf16", "commu_gemm_tn_bf16_grouped", "commu_relattn_bwd_band"]
     # (4 event pairs per entry-point call: ~1 us each on the host, < 2% of a step)
     _lib.profile_start(prof_names)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    run(steps, warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -254,6 +254,92 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
+    del trainer, model, batches
+    torch.cuda.empty_cache()
+    return elapsed, tokens_per_step, prof
+
+
+def attention_roofline(args, prof, tokens_per_step, elapsed):
+    """Roofline of the dominant SINGLE kernel: the three attention entry points launch exactly one kernel at one
+    shape (the GEMM entry points are a mix of shapes and tile variants; their share is in time_share).
+    Algorithmic flops per launch = tokens * products * 2*Kbar*D  (Kbar = M + (T+1)/2):
+      forward 3 products (QK^T, QR^T, PV); query-stationary backward 4 (QK^T, QR^T, dP, dQ);
+      key-stationary backward 5 (QK^T, QR^T, dP, dV, dK)."""
+    T, M = args.tgt_len, args.mem_len
+    mb_tokens = tokens_per_step // args.batch_chunk
+    kbar = M + (T + 1) / 2.0
+    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 5.0}
+    tot = {k: sum(v) for k, v in prof.items()}
+    cnt = {k: max(1, len(v)) for k, v in prof.items()}
+    dom = max(products, key=lambda k: tot.get(k, 0.0))
+    fl_launch = mb_tokens * products[dom] * 2.0 * kbar * args.d_model
+    avg_ms = tot[dom] / cnt[dom]
+    achieved = fl_launch / (avg_ms * 1e-3) / 1e12
+    return {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom, args),
+            "flops_per_launch": fl_launch, "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
+            "time_share": {k: round(tot[k] / (1e3 * elapsed), 4) for k in tot if tot[k] > 0}}
+
+
+# Further single-GPU rows (VERDICT r1: the shapes that were parity-tested but never timed); a few steps each
+EXTRA_ROWS = [
+    # tag, overrides
+    ("L6_D512_T1024_mem1024", dict(mem_len=1024)),
+    ("reference_default_L6_D500_dh50_DI1000_T128_M1024_b256_chunk4",
+     dict(d_model=500, heads=10, d_inner=1000, tgt_len=128, mem_len=1024, batch_per_gpu=256, batch_chunk=4)),
+    ("cfg5_L12_D1024_H16_DI2048_T2048_M2048_b8_bf16",
+     dict(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048, batch_per_gpu=8)),
+]
+
+
+def extra_rows(args, dev):
+    rows = {}
+    for tag, over in EXTRA_ROWS:
+        a = argparse.Namespace(**{**vars(args), **over})
+        steps, warmup = 4, 2
+        elapsed, tps, prof = train_bench(a, dev, 1, 0, steps, warmup)
+        f = 3.0 * fwd_flops_per_token(a.layers, a.d_model, a.d_inner, a.tgt_len, a.mem_len) * tps
+        rows[tag] = {"value": round(tps * steps / elapsed, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
+                     "steps": steps, "warmup": warmup, "tokens_per_step": tps,
+                     "step_mfma_frac": round(f / (elapsed / steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+                     "roofline": attention_roofline(a, prof, tps, elapsed)}
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--d-model", dest="d_model", type=int, default=512)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--d-inner", dest="d_inner", type=int, default=1024)
+    ap.add_argument("--tgt-len", dest="tgt_len", type=int, default=1024)
+    ap.add_argument("--mem-len", dest="mem_len", type=int, default=0)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--batch-chunk", type=int, default=1)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU shape rows")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="weight-gradient work on the main stream (default: a side stream)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    B = args.batch_per_gpu
+    elapsed, tokens_per_step, prof = train_bench(args, dev, world, rank, args.steps, args.warmup)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -264,21 +350,6 @@ def main():
     L, D, DI, T, M, H = args.layers, args.d_model, args.d_inner, args.tgt_len, args.mem_len, args.heads
     f_fwd = fwd_flops_per_token(L, D, DI, T, M)
     step_flops = 3.0 * f_fwd * tokens_per_step
-    # Roofline of the dominant SINGLE kernel: the three attention entry points launch exactly one kernel at one
-    # shape (the GEMM entry points are a mix of shapes and tile variants; their share is in time_share).
-    # Algorithmic flops per launch = tokens * products * 2*Kbar*D  (Kbar = M + (T+1)/2):
-    #   forward 3 products (QK^T, QR^T, PV); query-stationary backward 4 (QK^T, QR^T, dP, dQ);
-    #   key-stationary backward 5 (QK^T, QR^T, dP, dV, dK).
-    mb_tokens = tokens_per_step // args.batch_chunk
-    kbar = M + (T + 1) / 2.0
-    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 5.0}
-    tot = {k: sum(v) for k, v in prof.items()}
-    cnt = {k: max(1, len(v)) for k, v in prof.items()}
-    dom = max(products, key=lambda k: tot.get(k, 0.0))
-    fl_launch = mb_tokens * products[dom] * 2.0 * kbar * D
-    avg_ms = tot[dom] / cnt[dom]
-    achieved = fl_launch / (avg_ms * 1e-3) / 1e12
-    traffic = pmc_traffic(dom, args)
     out = {
         "metric": "training tokens/sec at d_model=512 tgt_len=1024",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -290,15 +361,11 @@ def main():
                    "weights": "random init (train.py:291-342)"},
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
-        "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "flops_per_launch": fl_launch,
-                     "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
-                     "time_share": {k: round(tot[k] / (1e3 * elapsed), 4) for k in tot}},
+        "roofline": attention_roofline(args, prof, tokens_per_step, elapsed),
     }
+    if world == 1 and not args.no_extra:
+        out["extra_rows"] = extra_rows(args, dev)
     if world == 1 and not args.no_decode:
-        del trainer, model
-        torch.cuda.empty_cache()
         out["decode"] = {"metric": "autoregressive decode tokens/sec (64 sequences in parallel, device-resident forcing "
                                    "+ K/V-cache step + top-k 32 / T 0.95 sampling in one hipGraph per iteration)",
                          "short_memory": decode_bench(dev, args, 11), "long_memory": decode_bench(dev, args, 1000),

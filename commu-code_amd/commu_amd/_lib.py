@@ -49,7 +49,8 @@ PROTOTYPES = {
     "commu_gemm_tn_bf16_grouped": [C.POINTER(TnProblem), c_i, c_i, c_p, C.c_longlong, c_i, c_p],
     "commu_reduce_slabs2d_f32": [c_p, c_i, C.c_longlong, c_p, c_i, c_i, c_i, c_z, c_i, c_i, c_f, c_p],
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
-    "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
+    "commu_reduce_slabs_crop_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_z, c_i, c_f, c_p],
+    "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
     "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, C.c_uint, c_f, c_p],
     "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_i, C.c_uint, c_f, c_p],
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "commu_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_transpose_f32_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_copy_bf16": [c_p, c_p, c_z, c_p],
+    "commu_mems_update": [c_p, c_z, c_z, c_z, c_p, c_z, c_z, c_z, c_p, c_z, c_i, c_p],
     "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p],
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_q": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],

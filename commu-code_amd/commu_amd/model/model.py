@@ -401,8 +401,8 @@ class MemTransformerLM(nn.Module):
         if not self._padded or mems is None or mems.numel() == 0 or mems.shape[-1] == self._Dp:
             return mems
         Lp, M, B, D = mems.shape
-        if mems.dtype == BF16 and mems.stride() == (M * B * self._Dp, B * self._Dp, self._Dp, 1):
-            return torch.as_strided(mems, (Lp, M, B, self._Dp), mems.stride())      # our own padded storage
+        if mems.dtype == BF16 and mems.stride()[1:] == (B * self._Dp, self._Dp, 1):
+            return torch.as_strided(mems, (Lp, M, B, self._Dp), mems.stride(), mems.storage_offset())   # our own padded storage
         out = torch.zeros(Lp, M, B, self._Dp, device=mems.device, dtype=BF16)
         out[..., :D].copy_(mems)
         return out
@@ -441,9 +441,10 @@ class MemTransformerLM(nn.Module):
         def ss(site):
             return ops.site_seed(seed, site)
 
-        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight, drop_p=p, drop_seed=ss(0), ld=D)     # K1
+        # every layer's output goes straight into one [L+1, T*B, Dp] buffer: it IS the list of hidden states K9 needs
+        hids = torch.empty(L + 1, TB, D, device=dev, dtype=BF16)
+        h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight, out=hids[0], drop_p=p, drop_seed=ss(0))    # K1
         pd = ops.posemb(self.pos_emb.inv_freq, K, Dt, drop_p=p, drop_seed=ss(1), ld=D)               # K2 (distance order)
-        hids = [h]
         if need_grad:
             sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
             sv.same_length, sv.mem_len = bool(self.same_length), int(self.mem_len)
@@ -475,7 +476,7 @@ class MemTransformerLM(nn.Module):
             if i == L - 1 and p > 0:          # final `self.drop(core_out)` (model.py:601) as a second LN output
                 h_out = torch.empty(TB, D, device=dev, dtype=BF16)
             y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias,
-                                            y_drop=h_out, drop_p=p, drop_seed=ss(2))
+                                            y=hids[i + 1], y_drop=h_out, drop_p=p, drop_seed=ss(2))
             if need_grad:
                 sv.h.append(h); sv.cat.append(cat); sv.qkv.append(qkv); sv.rd.append(rd); sv.vec.append(vec)
                 sv.lse.append(lse); sv.qs.append(qs); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1)
@@ -483,7 +484,6 @@ class MemTransformerLM(nn.Module):
             if want_kv:
                 kv_out.append(qkv)
             h = y
-            hids.append(h)
         if h_out is None:
             h_out = h
 
@@ -499,23 +499,23 @@ class MemTransformerLM(nn.Module):
         return nll.view(T, B), new_mems, sv
 
     def _update_mems(self, hids, mems, M, T, B):                                 # model.py:507-538
+        """K9.  hids: [L+1, T*B, Dp] (written in place by the forward pass).  new_mems[l] = cat(mems[l], hids[l])[beg:end];
+        with tgt_len >= mem_len that is a VIEW of hids (no copy), otherwise one commu_mems_update launch."""
         if mems is None:
             return None
-        with torch.no_grad():
-            end = M + T
-            beg = max(0, end - self.mem_len)
-            n = end - beg
-            Dp = self._Dp
-            out = torch.empty(len(hids), n, B, Dp, device=hids[0].device, dtype=BF16)
-            for i, hcur in enumerate(hids):
-                hv = hcur.view(T, B, Dp)
-                if beg >= M:
-                    out[i].copy_(hv[beg - M:])
-                else:
-                    out[i, :M - beg].copy_(mems[i][beg:])
-                    out[i, M - beg:].copy_(hv)
-            # (padded shapes: the caller sees the reference's [L+1, n, B, d_model]; the view keeps the padded storage)
-            return out[..., :self.d_model] if self._padded else out
+        end = M + T
+        beg = max(0, end - self.mem_len)
+        n = end - beg
+        Lp, Dp = hids.shape[0], self._Dp
+        if beg >= M:
+            out = hids.view(Lp, T, B, Dp)[:, beg - M:]
+        else:
+            if mems.dtype != BF16 or mems.stride()[1:] != (B * Dp, Dp, 1):
+                mems = mems.to(BF16).contiguous()
+            out = torch.empty(Lp, n, B, Dp, device=hids.device, dtype=BF16)
+            ops.mems_update(hids, mems, out, beg)
+        # (padded shapes: the caller sees the reference's [L+1, n, B, d_model]; the view keeps the padded storage)
+        return out[..., :self.d_model] if self._padded else out
 
     # ------------------------------------------------------------------ backward schedule
     def _run_backward(self, sv, dloss):
@@ -729,9 +729,7 @@ class MemTransformerLM(nn.Module):
             if crop is not None:
                 rg, rt, rp, cg, ct, cp = crop
                 assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)
-                tmp = torch.empty(N * Kc, device=fl["dev"], dtype=F32)
-                ops.reduce_slabs(tmp, slabs[off:], N * Kc, ns, total, False, 1.0)
-                gW.view(rg, rt, cg, ct).add_(tmp.view(rg, rp, cg, cp)[:, :rt, :, :ct])
+                ops.reduce_slabs_crop(gW, slabs[off:], crop, ns, total, True)
             else:
                 nrows = N if rows is None else rows
                 ops.reduce_slabs(gW, slabs[off:], nrows * Kc, ns, total, True, 1.0)
@@ -752,9 +750,7 @@ class MemTransformerLM(nn.Module):
         if crop is not None:
             rg, rt, rp, cg, ct, cp = crop
             assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)
-            tmp = torch.empty(N * Kc, device=fl["dev"], dtype=F32)
-            ops.reduce_slabs(tmp, fl["slabs"], N * Kc, ns, N * Kc, False, 1.0)
-            gW.view(rg, rt, cg, ct).add_(tmp.view(rg, rp, cg, cp)[:, :rt, :, :ct])
+            ops.reduce_slabs_crop(gW, fl["slabs"], crop, ns, N * Kc, True)
             return
         nrows = N if rows is None else rows
         ops.reduce_slabs(gW, fl["slabs"], nrows * Kc, ns, N * Kc, True, 1.0)

@@ -28,15 +28,29 @@ def site_seed(base_seed: int, site: int) -> int:
     return x
 
 
-def dropout_keep_mask(seed: int, n: int, p: float, device="cpu"):
-    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests)."""
-    idx = (torch.arange(n, dtype=torch.int64, device=device) + seed) & 0xFFFFFFFF
-    x = idx
+def _mix32(x):
+    x = x & 0xFFFFFFFF
     x = x ^ (x >> 16)
     x = (x * 0x7feb352d) & 0xFFFFFFFF
     x = x ^ (x >> 15)
     x = (x * 0x846ca68b) & 0xFFFFFFFF
+    return x ^ (x >> 16)
+
+
+def _mix32k(x, key):
+    x = x & 0xFFFFFFFF
     x = x ^ (x >> 16)
+    x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x = x ^ key                               # the key enters between the two multiply rounds (common.cuh mix32k)
+    x = x ^ (x >> 15)
+    x = (x * 0x846ca68b) & 0xFFFFFFFF
+    return x ^ (x >> 16)
+
+
+def dropout_keep_mask(seed: int, n: int, p: float, device="cpu"):
+    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests; common.cuh drop_keep)."""
+    key = int(_mix32(torch.tensor(int(seed) & 0xFFFFFFFF, dtype=torch.int64)))
+    x = _mix32k(torch.arange(n, dtype=torch.int64, device=device), key)
     thr = min(int(p * 4294967296.0), 4294967295) if p > 0 else 0
     return x >= thr
 BF16 = torch.bfloat16
@@ -59,23 +73,26 @@ def _s():
 
 
 def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float):
-    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests): rows 2r and 2r+1
-    share the hash word of (r, j) -- low / high 16 bits -- compared with round(p * 65536)."""
+    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests; relattn.hip DropLane).
+    Every 16x16 block (i>>4, j>>4) of a (batch, head) has a 32-bit key from the strong hash (scalar work in the
+    kernels); inside the block a cheap two-round 24-bit multiply hash of (row pair, column) gives one word per two
+    rows: low 16 bits -> even row, high 16 bits -> odd row, compared with round(p * 65536)."""
     thr = max(1, int(p * 65536.0 + 0.5)) if p > 0 else 0
     out = torch.empty(B, H, T, K, dtype=torch.bool)
-    rows = torch.arange(T, dtype=torch.int64)
-    cols = torch.arange(K, dtype=torch.int64)
-    idx = (rows[:, None] >> 1) * K + cols[None, :]
+    rows = torch.arange(T, dtype=torch.int64)[:, None]
+    cols = torch.arange(K, dtype=torch.int64)[None, :]
+    blk = ((rows >> 4) << 16) | (cols >> 4)
+    xc = ((((rows & 15) >> 1) << 4) | (cols & 15)) * 0xD2B74B
     for b in range(B):
         for h in range(H):
-            sbh = (seed + (b * H + h) * 0x9E3779B1) & 0xFFFFFFFF
-            x = (idx + sbh) & 0xFFFFFFFF
-            x = x ^ (x >> 16)
-            x = (x * 0x7feb352d) & 0xFFFFFFFF
-            x = x ^ (x >> 15)
-            x = (x * 0x846ca68b) & 0xFFFFFFFF
-            x = x ^ (x >> 16)
-            half = (x >> (16 * (rows[:, None] & 1))) & 0xFFFF
+            key_bh = int(_mix32(torch.tensor((seed + (b * H + h) * 0x9E3779B1) & 0xFFFFFFFF, dtype=torch.int64)))
+            k1 = _mix32k(blk, key_bh)
+            k2 = (k1 * 0x85EBCA6B + 0x6A09E667) & 0xFFFFFFFF
+            y = (xc + k1) & 0xFFFFFFFF
+            y = y ^ (y >> 12)
+            y = ((y & 0xFFFFFF) * 0x9E3779 + k2) & 0xFFFFFFFF
+            y = y ^ (y >> 15)
+            half = (y >> (16 * (rows & 1))) & 0xFFFF
             out[b, h] = half >= thr
     return out, 1.0 - thr / 65536.0
 
@@ -212,6 +229,16 @@ def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate, alpha=1.0):
     return dst
 
 
+def reduce_slabs_crop(dst, slabs, crop, nslabs, stride, accumulate, alpha=1.0):
+    """crop = (rg, rt, rp, cg, ct, cp): the [rt, ct] blocks of the padded [rg*rp, cg*cp] product (summed over the
+    slabs) are added to / stored in dst [rg*rt, cg*ct]."""
+    rg, rt, rp, cg, ct, cp = crop
+    assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() == rg * rt * cg * ct
+    call("commu_reduce_slabs_crop_f32", _p(dst), _p(slabs), rg, rt, rp, cg, ct, cp, nslabs, stride,
+         1 if accumulate else 0, float(alpha), _s())
+    return dst
+
+
 def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0, ld=None):
     """ld > D: rows are padded to ld columns (zero-padding contract of commu_hip.h)."""
     ntok = tok.numel()
@@ -219,7 +246,7 @@ def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0, ld=None):
     assert tok.dtype == torch.int64 and E.dtype == F32 and E.is_contiguous() and tok.is_contiguous()
     if out is None:
         out = torch.empty(ntok, D if ld is None else ld, device=E.device, dtype=BF16)
-    call("commu_embed_fwd", _p(tok), _p(E), _p(out), out.stride(0), ntok, D, math.sqrt(D), int(drop_seed),
+    call("commu_embed_fwd", _p(tok), _p(E), _p(out), out.stride(0), ntok, D, E.shape[0], math.sqrt(D), int(drop_seed),
          float(drop_p), _s())
     return out
 
@@ -294,6 +321,19 @@ def ce_bwd(logits, target, lse, g, V, dlogits=None):
     call("commu_ce_bwd", _p(logits), logits.stride(0), _p(target), _p(lse), _p(g), _p(dlogits), dlogits.stride(0),
          rows, V, _s())
     return dlogits
+
+
+def mems_update(hids, mems, out, beg):
+    """K9: out[l] = cat(mems[l], hids[l])[beg:]  with hids [L+1, T*B, Dp], mems [L+1, M, B, Dp] (layer stride free),
+    out [L+1, n, B, Dp] contiguous, 0 <= beg < M."""
+    Lp, _, B, Dp = out.shape
+    M = mems.shape[1]
+    step = B * Dp
+    assert 0 <= beg < M and hids.shape[0] == Lp == mems.shape[0] and out.is_contiguous()
+    assert out.shape[1] * step == (M - beg) * step + hids.shape[1] * Dp
+    call("commu_mems_update", _p(hids), hids.stride(0), 0, hids.shape[1] * Dp, _p(mems), mems.stride(0), beg * step,
+         (M - beg) * step, _p(out), out.stride(0), Lp, _s())
+    return out
 
 
 def masked_mean(nll, target, pad, scale, ws_sum, ws_cnt, out):

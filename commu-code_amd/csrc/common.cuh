@@ -81,13 +81,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // K16 dropout: counter-based mask, identical in forward and backward.  keep(seed, idx) is a 32-bit
-// integer hash (lowbias32) of the element index compared with p * 2^32; kept values are scaled by
+// integer hash (lowbias32, keyed by the seed) of the element index compared with p * 2^32; kept values are scaled by
 // 1/(1-p) (nn.Dropout semantics, commu/model/model.py:166,168,210-211,454,585-586,601).
 __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned idx, unsigned thr) { return mix32(idx + seed) >= thr; }
+// keyed form: the seed enters BETWEEN the two multiply rounds, so the masks of two seeds are related by a
+// pseudo-random permutation of the index space, never by a shift of it (with mix32(idx + seed) two dropout sites whose
+// seeds differ by less than the tensor size would have used shifted copies of one mask)
+__device__ __forceinline__ unsigned mix32k(unsigned idx, unsigned key) {
+    unsigned x = idx;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= key; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// (the key itself is mixed first -- wave-uniform, so it costs scalar instructions once -- because seeds that differ
+//  only in a few low bits would otherwise change the second round's input by a near-constant)
+__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned idx, unsigned thr) { return mix32k(idx, mix32(seed)) >= thr; }
 
 __device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *(const bf16x8*)p; }
 __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *(bf16x8*)p = v; }

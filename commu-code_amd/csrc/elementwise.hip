@@ -10,12 +10,16 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // K1: x[m,:] = E[tok[m],:] * sqrt(D)       (commu/model/model.py:409-420)
 __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ E,
-                                 bf16* __restrict__ out, int ldo, int ntok, int D, float scale,
+                                 bf16* __restrict__ out, int ldo, int ntok, int D, int V, float scale,
                                  unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= ntok) return;
     const int lane = threadIdx.x & 63;
-    const float* src = E + (size_t)tok[m] * D;
+    // an id outside the vocabulary (the reference's nn.Embedding raises IndexError) poisons its row with NaN: the
+    // loss of that step is NaN instead of a read through a wild pointer
+    const long long id = tok[m];
+    const bool bad = id < 0 || id >= V;
+    const float* src = E + (size_t)(bad ? 0 : id) * D;
     bf16* dst = out + (size_t)m * ldo;
     const int Dz = min(ldo, (D + 63) & ~63);          // zero-padding contract: columns [D, Dz) are written as 0
     for (int c = lane * 4; c < Dz; c += 256) {
@@ -24,7 +28,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = v[e] * scale;
+            float x = bad ? __builtin_nanf("") : v[e] * scale;
             if (drop_thr) x = drop_keep(drop_seed, (unsigned)m * (unsigned)D + (unsigned)(c + e), drop_thr) ? x * drop_scale : 0.f;
             o[e] = f2bf(x);
         }
@@ -392,7 +396,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const float l = mx + logf(s);
     if (lane == 0) {
         lse[row] = l;
-        nll[row] = l - p[target[row]];
+        const long long tg = target[row];          // (outside [0, V): NaN, the reference's gather would raise)
+        nll[row] = (tg >= 0 && tg < V) ? l - p[tg] : __builtin_nanf("");
     }
 }
 
@@ -558,12 +563,12 @@ static inline unsigned drop_threshold(float p) {
     return p <= 0.f ? 0u : (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
 }
 
-extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, int ldo, int ntok, int D,
+extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, int ldo, int ntok, int D, int V,
                                float scale, unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (ntok <= 0) return 0;
     if (D % 4) return -22;
     COMMU_LAUNCH(embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, stream, tok, E, (bf16*)out,
-                       ldo, ntok, D, scale, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                       ldo, ntok, D, V, scale, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -778,6 +783,40 @@ extern "C" int commu_copy_bf16(const void* src, void* dst, size_t n, hipStream_t
     if (n % 8) return -22;
     COMMU_LAUNCH(copy_rows_kernel, dim3(cap_blocks((n / 8 + 255) / 256)), dim3(256), 0, stream,
                        (const bf16*)src, (bf16*)dst, n / 8);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K9: memory update (reference model.py:507-538  _update_mems: new_mems[l] = cat([mems[l], hids[l]])[beg:end]).
+// One launch for all L+1 layers: out[l] = [ mems[l][mem_skip : mem_skip + keep) ; hids[l][hid_skip : hid_skip + take) ]
+// (element counts, multiples of 8 -- rows are whole [B, Dp] time steps).  16-byte copies, HBM-bound:
+// (keep + take) * 2 bytes read + the same written per layer.  When tgt_len >= mem_len nothing is copied at all: the
+// forward writes every layer's output into one [L+1, T, B, Dp] buffer and the new memory is a view of it.
+__global__ void __launch_bounds__(256) mems_update_kernel(const bf16* __restrict__ hids, size_t hid_stride, size_t hid_skip,
+                                                          size_t take, const bf16* __restrict__ mems, size_t mem_stride,
+                                                          size_t mem_skip, size_t keep, bf16* __restrict__ out,
+                                                          size_t out_stride) {
+    const int l = blockIdx.y;
+    const uint4* m = reinterpret_cast<const uint4*>(mems + (size_t)l * mem_stride + mem_skip);
+    const uint4* h = reinterpret_cast<const uint4*>(hids + (size_t)l * hid_stride + hid_skip);
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)l * out_stride);
+    const size_t nk = keep / 8, n = nk + take / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        o[i] = i < nk ? m[i] : h[i - nk];
+}
+
+extern "C" int commu_mems_update(const void* hids, size_t hid_stride, size_t hid_skip, size_t take, const void* mems,
+                                 size_t mem_stride, size_t mem_skip, size_t keep, void* out, size_t out_stride,
+                                 int layers, hipStream_t stream) {
+    if (layers <= 0 || keep + take == 0) return 0;
+    if ((hid_stride | hid_skip | take | mem_stride | mem_skip | keep | out_stride) % 8) return -22;
+    if ((keep && !mems) || (take && !hids) || !out) return -22;
+    const size_t n = (keep + take) / 8;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 2048 / layers + 1) bx = 2048 / layers + 1;
+    COMMU_LAUNCH(mems_update_kernel, dim3(bx, layers), dim3(256), 0, stream, (const bf16*)hids, hid_stride, hid_skip, take,
+                 (const bf16*)mems, mem_stride, mem_skip, keep, (bf16*)out, out_stride);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -814,6 +814,39 @@ extern "C" int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch
     return 0;
 }
 
+// Cropping reduce for zero-padded weight gradients (d_head 50 -> 64, d_model 500 -> 512): the product has the padded
+// shape [rg*rp, cg*cp]; its [rt, ct] blocks go to dst [rg*rt, cg*ct]:
+//   dst[((a*rt + r)*cg + c)*ct + k] (+)= alpha * sum_s src[s*stride + ((a*rp + r)*cg + c)*cp + k]
+__global__ void reduce_slabs_crop_kernel(float* __restrict__ dst, const float* __restrict__ src, int rg, int rt, int rp,
+                                         int cg, int ct, int cp, int nslabs, size_t stride, int accumulate, float alpha) {
+    const size_t n = (size_t)rg * rt * cg * ct;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ct);
+        size_t q = i / ct;
+        const int c = (int)(q % cg);
+        q /= cg;
+        const int r = (int)(q % rt), a = (int)(q / rt);
+        const size_t j = (((size_t)a * rp + r) * cg + c) * cp + k;
+        float v = src[j];
+        for (int z = 1; z < nslabs; ++z) v += src[(size_t)z * stride + j];
+        v *= alpha;
+        if (accumulate) v += dst[i];
+        dst[i] = v;
+    }
+}
+
+extern "C" int commu_reduce_slabs_crop_f32(float* dst, const float* src, int rg, int rt, int rp, int cg, int ct, int cp,
+                                           int nslabs, size_t stride, int accumulate, float alpha, hipStream_t stream) {
+    if (rg <= 0 || rt <= 0 || cg <= 0 || ct <= 0) return 0;
+    if (rt > rp || ct > cp || nslabs <= 0) return -22;
+    size_t blocks = ((size_t)rg * rt * cg * ct + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    COMMU_LAUNCH(reduce_slabs_crop_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, rg, rt, rp, cg, ct, cp,
+                 nslabs, stride, accumulate, alpha);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- grouped weight-gradient GEMM (gemm8.hip: gemm_tn8_kernel)
 static bool tn_group_plan(const commu_tn_problem* probs, int nprob, int M, Tn8Args* out) {
     if (nprob <= 0 || nprob > 8) return false;

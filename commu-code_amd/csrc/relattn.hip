@@ -54,8 +54,7 @@ struct AttnArgs {
     int T, M, B, H;
     int same_length, sshift;
     float scale;
-    unsigned drop_seed, drop_thr;   // attention-probability dropout: 16-bit threshold (0: off); rows 2r, 2r+1
-                                    // share the hash word mix32(seed_bh + r*K + j), low / high half
+    unsigned drop_seed, drop_thr;   // attention-probability dropout: 16-bit threshold (0: off), see DropLane
     float drop_scale;
 };
 
@@ -108,6 +107,40 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* img, int kbase, int r16, i
         f[4 * h + 0] = v[0]; f[4 * h + 1] = v[1]; f[4 * h + 2] = v[2]; f[4 * h + 3] = v[3];
     }
     return f;
+}
+
+// Attention-probability dropout (K16).  keep(b,h,i,j): every 16x16 block (i>>4, j>>4) of a (batch, head) pair has a
+// 32-bit key from the strong hash -- block coordinates are wave-uniform in all three kernels, so that is SCALAR work
+// -- and inside the block a cheap two-round hash on full-rate 24-bit multiplies of (row pair, column) gives one word
+// per two rows: low 16 bits -> even row, high 16 bits -> odd row, compared with the 16-bit threshold.  (The previous
+// form, one 32-bit lowbias hash per word on the vector unit, cost two quarter-rate v_mul_lo_u32 and ~11 more VALU
+// instructions per word: a quarter of the forward kernel's time.)  Host mirror: ops.attn_dropout_keep_mask.
+constexpr unsigned DROP_C1 = 0xD2B74Bu, DROP_C2 = 0x9E3779u;
+struct DropLane {
+    unsigned xc[2];        // ((row pair 2g+rp) << 4 | column r16) * C1 : the lane's two words of any block (C layout)
+    unsigned key_bh;
+    __device__ __forceinline__ void init(unsigned seed, int b, int h, int H, int g, int r16) {
+        key_bh = mix32(seed + (unsigned)(b * H + h) * 0x9E3779B1u);
+        xc[0] = (unsigned)(((2 * g) << 4) | r16) * DROP_C1;
+        xc[1] = (unsigned)(((2 * g + 1) << 4) | r16) * DROP_C1;
+    }
+    // hash words of block (ib, jb) = (i >> 4, j >> 4); both must be wave-uniform
+    __device__ __forceinline__ void words(int ib, int jb, unsigned (&hw)[2]) const {
+        const unsigned k1 = mix32k(((unsigned)ib << 16) | (unsigned)jb, key_bh);
+        const unsigned k2 = k1 * 0x85EBCA6Bu + 0x6A09E667u;
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            unsigned y = xc[rp] + k1;
+            y ^= y >> 12;
+            y = (y & 0xFFFFFFu) * DROP_C2 + k2;
+            y ^= y >> 15;
+            hw[rp] = y;
+        }
+    }
+};
+// reg = row 4g+reg of the block: even rows take the low half of word reg>>1, odd rows the high half
+__device__ __forceinline__ bool drop_keep16(const unsigned (&hw)[2], int reg, unsigned thr, unsigned thr_hi) {
+    return (reg & 1) ? hw[reg >> 1] >= thr_hi : (unsigned short)hw[reg >> 1] >= (unsigned short)thr;
 }
 
 __device__ __forceinline__ float bperm(int addr, float v) {
@@ -206,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
     __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sP[NW * 64 * PT];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
     const int QT = (a.T + QROWS - 1) / QROWS;
     // A workgroup takes the query tiles q and QT-1-q of its (batch, head) pair back to back: every workgroup walks the
     // same number of key tiles (the causal triangle folded in half), and half as many workgroups are launched.
@@ -218,7 +251,9 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
     if (rep == 1 && qt >= QT - 1 - qslot) break;          // odd tile count: the middle tile is done once
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
+    DropLane dl_;
+    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    const unsigned thr_hi = a.drop_thr << 16;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;           // bytes between consecutive kv rows
     const float c2 = a.scale * LOG2E;
 
@@ -357,16 +392,12 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
         for (int c = 0; c < 4; ++c) {
             bf16x4 pb;
             unsigned hw[2] = {0u, 0u};
-            if (DROP) {          // one hash word per (row pair, column): 16 bits per element
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp)
-                    hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
-            }
+            if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 float p = __builtin_amdgcn_exp2f(s[c][reg] - mrow[reg]);
                 lpart[reg] += p;                               // the normaliser is the un-dropped sum
-                if (DROP) p = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? p * a.drop_scale : 0.f;
+                if (DROP) p = drop_keep16(hw, reg, a.drop_thr, thr_hi) ? p : 0.f;      // 1/(1-p) is applied to O at the end
                 pb[reg] = f2bf(p);
             }
             *(bf16x4*)(myP + pt_off(16 * c + r16, g)) = pb;       // P^T[kv][row]: rows 4g..4g+3
@@ -390,7 +421,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const float l = row16_sum(lpart[reg]);
-        const float inv = 1.f / l;
+        const float inv = (DROP ? a.drop_scale : 1.f) / l;
         const int i = i0 + 16 * w + 4 * g + reg;
         if (i < T) {
             bf16* op = a.out + ((size_t)i * B + b) * a.ld_o + h * DH;
@@ -398,6 +429,277 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
             for (int d = 0; d < DB; ++d) op[16 * d + r16] = f2bf(o[d][reg] * inv);
             if (r16 == 0) a.lse[((size_t)b * a.H + h) * T + i] = (mrow[reg] + __log2f(l)) * LN2;
         }
+    }
+    }
+}
+
+// =============================================================================================
+// Forward, second generation (d_head 64).  Measured on the first-generation kernel above (rocprofv3 PMC, bench
+// shape): the VALU is the busiest pipe (~50 %), the MFMA pipe 12 %, and at 192 VGPRs only two waves share a SIMD, so
+// nothing hides anything.  This kernel is built around that:
+//  * 8 waves x 16 rows = 128 query rows per workgroup, <= 128 VGPRs, two workgroups per CU: four waves per SIMD;
+//  * K / V / band tiles arrive by LDS-DMA (buffer_load ... lds; the XOR swizzle is applied on the SOURCE side, the LDS
+//    image is lane-linear) into double buffers (the band: a ring of four 64-distance chunks, one new chunk per tile):
+//    no staging registers, no LDS store instructions, ONE barrier per key tile;
+//  * the softmax is written for instruction count: max3 + DPP-fused row maxima from asm (no canonicalising v_max, no
+//    v_mov_dpp), packed subtract / add, the keep-scale of the dropout applied once to O, block-keyed dropout words;
+//  * O leaves through the wave's P buffer as whole 128-byte rows.
+__device__ __forceinline__ float vmax3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// maxima over the 16 lanes of each DPP row, four values at once: the four chains interleave, which covers the two
+// wait states a DPP read needs after the VALU write of its source
+__device__ __forceinline__ void row16_max4(float& x0, float& x1, float& x2, float& x3) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+}
+__device__ __forceinline__ void lds_dma16(srd_t srd, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(srd) : "memory");
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+template <bool DROP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void relattn_fwd2_kernel(const AttnArgs a) {
+    constexpr int DH = 64, NW = 8, QROWS = 128, TILE = 64 * DH, KS = 2, DB = 4;
+    __shared__ __attribute__((aligned(1024))) bf16 smem[8 * TILE + NW * 64 * PT];          // 64 + 16 KB
+    bf16* const sK = smem;                     // [2][64 keys][64]
+    bf16* const sV = smem + 2 * TILE;          // [2][64 keys][64]
+    bf16* const sR = smem + 4 * TILE;          // [4][64 distances][64]  ring of band chunks
+    bf16* const sP = smem + 8 * TILE;          // per wave: P^T image [64 keys][16 rows], then the O tile [16 rows][64]
+    const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+    const int T = a.T, M = a.M, B = a.B, K = T + M;
+    const int QT = (T + QROWS - 1) / QROWS, QH = (QT + 1) / 2;
+    int qslot, h, b;
+    tile_coords(QH, a.H, B, qslot, h, b);
+    const bool rst = a.reset != nullptr && a.reset[b] != 0;
+    DropLane dl_;
+    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    const unsigned thr_hi = a.drop_thr << 16;
+    const unsigned rsb = (unsigned)B * a.ld_qkv * 2u, rdb = (unsigned)a.ld_rd * 2u;
+    const float c2 = a.scale * LOG2E;
+    const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
+    const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
+    // LDS-DMA: wave w stages rows 8w..8w+7 of every 64-row tile (one 1 KB instruction per tile and operand); lane l
+    // lands at byte 16 l of the wave's slice = row 8w + (l >> 3), physical chunk l & 7, so it fetches source chunk
+    // (l & 7) ^ (row & 7).  Rows outside the tensor are outside the descriptor: zeros.
+    const int drow = 8 * w + (lane >> 3);
+    const unsigned dchunk = (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
+    const unsigned ldsK = lds0 + (unsigned)w * 1024u, ldsV = ldsK + 2u * TILE * 2u, ldsR = ldsK + 4u * TILE * 2u;
+    // fragment addressing (elements): row part r16 * 64 + swizzled 16-byte chunk; tile rows are multiples of 16 further
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r16 * DH + (((4 * ks + g) ^ (r16 & 7)) << 3);
+    int srcaddr[4];
+    bool lower[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
+        lower[reg] = r16 < 4 * g + reg;
+    }
+    bf16* const myP = sP + w * 64 * PT;
+
+    for (int rep = 0; rep < 2; ++rep) {
+    const int qt = rep == 0 ? QT - 1 - qslot : qslot;
+    if (rep == 1 && qt >= QT - 1 - qslot) break;          // odd tile count: the middle tile is done once
+    const int i0 = qt * QROWS;
+    const int iw_lo = i0 + 16 * w, iw_hi = iw_lo + 15;
+    int jt_lo, jt_hi;
+    kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
+    if (rep == 1) __syncthreads();                        // the first tile's buffers are free
+    auto stage = [&](int jt, int tt, int chunk) {          // K, V tile jt and band chunk `chunk` of that tile
+        const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
+        const unsigned kvoff = (unsigned)(j0 + drow) * rsb + dchunk;
+        lds_dma16(srdK, kvoff, ldsK + (unsigned)(tt & 1) * (TILE * 2u));
+        lds_dma16(srdV, kvoff, ldsV + (unsigned)(tt & 1) * (TILE * 2u));
+        lds_dma16(srdR, (unsigned)(dlo + 64 * chunk + drow) * rdb + dchunk, ldsR + (unsigned)((chunk - tt) & 3) * (TILE * 2u));
+    };
+    {   // prologue: upper band chunks of the first tile, then the tile itself
+        const int dlo = i0 + M - jt_lo * 64 - 63;
+        lds_dma16(srdR, (unsigned)(dlo + 64 + drow) * rdb + dchunk, ldsR + 1u * (TILE * 2u));
+        lds_dma16(srdR, (unsigned)(dlo + 128 + drow) * rdb + dchunk, ldsR + 2u * (TILE * 2u));
+        stage(jt_lo, 0, 0);
+    }
+
+    bf16x8 qu[KS], qv[KS];
+    {
+        const int irow = iw_lo + r16;
+        const int iq = min(irow, T - 1);
+        const bf16* qp = a.q + ((size_t)iq * B + b) * a.ld_qkv + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 raw = ld_bf16x8(qp + 32 * ks + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = h * DH + 32 * ks + 8 * g + e;
+                const float x = bf2f(raw[e]);
+                qu[ks][e] = f2bf((x + a.u[f]) * c2);
+                qv[ks][e] = f2bf((x + a.vb[f]) * c2);
+            }
+            if (a.qu2 != nullptr && irow < T) {
+                const size_t off = ((size_t)irow * B + b) * (a.H * DH) + h * DH + 32 * ks + 8 * g;
+                st_bf16x8(a.qu2 + off, qu[ks]);
+                st_bf16x8(a.qv2 + off, qv[ks]);
+            }
+        }
+    }
+    f32x4 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrow[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    f32x2 lp01 = {0.f, 0.f}, lp23 = {0.f, 0.f};
+
+    for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
+        const int j0 = jt * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t has landed
+        __builtin_amdgcn_s_barrier();                            // ... everybody's has; tile t-1 is no longer read
+        if (jt < jt_hi) stage(jt + 1, t + 1, 0);
+        // a wave whose 16 rows see nothing of this key tile only takes part in the staging
+        if (j0 > iw_hi + M || (a.same_length && j0 + 63 <= iw_lo - a.sshift) || iw_lo >= T) continue;
+        const bf16* tK = sK + (t & 1) * TILE;
+        const bf16* tV = sV + (t & 1) * TILE;
+
+        f32x4 qr[5];
+#pragma unroll
+        for (int blk = 0; blk < 5; ++blk) {
+            qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int x = 16 * w + 16 * blk;                  // band row of the block; chunk x >> 6 sits in slot (chunk - t) & 3
+            const bf16* rb = sR + ((((x >> 6) - t) & 3) * 64 + (x & 63)) * DH;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], ld_bf16x8(rb + foff[ks]), qr[blk]);
+        }
+        f32x4 s[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
+                        t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
+            s[0][reg] = bperm(srcaddr[reg], t0);
+            s[1][reg] = bperm(srcaddr[reg], t1);
+            s[2][reg] = bperm(srcaddr[reg], t2);
+            s[3][reg] = bperm(srcaddr[reg], t3);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[c] = mfma16(qu[ks], ld_bf16x8(tK + 16 * c * DH + foff[ks]), s[c]);
+        }
+        const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
+                               (rst && j0 < M) || (iw_hi >= T);
+        if (need_mask) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = iw_lo + 4 * g + reg;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst)) s[c][reg] = -INFINITY;
+            }
+        }
+        // online softmax (log2 domain); rescale only when some row's running max moved
+        float mx[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) mx[reg] = vmax2(vmax3(s[0][reg], s[1][reg], s[2][reg]), s[3][reg]);
+        row16_max4(mx[0], mx[1], mx[2], mx[3]);
+        bool grew = false;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            mx[reg] = vmax2(mrow[reg], mx[reg]);
+            grew |= mx[reg] > mrow[reg];
+        }
+        if (__any(grew)) {
+            float al[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                al[reg] = __builtin_amdgcn_exp2f(mrow[reg] - mx[reg]);
+                mrow[reg] = mx[reg];
+#pragma unroll
+                for (int d = 0; d < DB; ++d) o[d][reg] *= al[reg];
+            }
+            lp01 *= (f32x2){al[0], al[1]};
+            lp23 *= (f32x2){al[2], al[3]};
+        }
+        const f32x2 m01 = {mrow[0], mrow[1]}, m23 = {mrow[2], mrow[3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned hw[2] = {0u, 0u};
+            if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
+            const f32x2 e01 = (f32x2){s[c][0], s[c][1]} - m01, e23 = (f32x2){s[c][2], s[c][3]} - m23;
+            f32x2 p01 = {__builtin_amdgcn_exp2f(e01[0]), __builtin_amdgcn_exp2f(e01[1])};
+            f32x2 p23 = {__builtin_amdgcn_exp2f(e23[0]), __builtin_amdgcn_exp2f(e23[1])};
+            lp01 += p01;                                        // the normaliser is the un-dropped sum
+            lp23 += p23;
+            if (DROP) {                                         // 1/(1-p) is applied to O at the end
+                p01[0] = drop_keep16(hw, 0, a.drop_thr, thr_hi) ? p01[0] : 0.f;
+                p01[1] = drop_keep16(hw, 1, a.drop_thr, thr_hi) ? p01[1] : 0.f;
+                p23[0] = drop_keep16(hw, 2, a.drop_thr, thr_hi) ? p23[0] : 0.f;
+                p23[1] = drop_keep16(hw, 3, a.drop_thr, thr_hi) ? p23[1] : 0.f;
+            }
+            bf16x4 pb;
+            pb[0] = f2bf(p01[0]); pb[1] = f2bf(p01[1]); pb[2] = f2bf(p23[0]); pb[3] = f2bf(p23[1]);
+            *(bf16x4*)(myP + pt_off(16 * c + r16, g)) = pb;       // P^T[kv][row]: rows 4g..4g+3
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (requesting the operand fragments ahead of their MFMAs -- source-level batching plus sched_group_barrier --
+        //  was measured: the extra live registers cost more than the exposed LDS latency at four waves per SIMD)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pf = frag_tr(myP, 32 * ks, r16, g);
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+                o[d] = mfma16(pf, frag_tr_rm<DH>(tV, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * d, r16), o[d]);
+        }
+        __builtin_amdgcn_wave_barrier();                         // P image is rewritten by the next tile
+    }
+    // epilogue: normalise, O through the wave's P buffer ([16 rows][64] bf16, 16-byte chunk c of row r at chunk
+    // c ^ (r & 7)), out as whole 128-byte rows; lse
+    {
+        float lr[4] = {lp01[0], lp01[1], lp23[0], lp23[1]};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float l = row16_sum(lr[reg]);
+            const float inv = (DROP ? a.drop_scale : 1.f) / l;
+            const int row = 4 * g + reg, i = iw_lo + row;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int col = 16 * d + r16;
+                myP[row * DH + ((((col >> 3) ^ (row & 7))) << 3) + (col & 7)] = f2bf(o[d][reg] * inv);
+            }
+            if (r16 == 0 && i < T) a.lse[((size_t)b * a.H + h) * T + i] = (mrow[reg] + __log2f(l)) * LN2;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int row = (lane >> 3) + 8 * n, ch = lane & 7, i = iw_lo + row;
+            if (i < T)
+                st_bf16x8(a.out + ((size_t)i * B + b) * a.ld_o + h * DH + 8 * ch, ld_bf16x8(myP + row * DH + ((ch ^ (row & 7)) << 3)));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     }
 }
@@ -414,27 +716,33 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sD[NW * 64 * PT];
     __shared__ float red[NW][DH];
-    // dS-by-distance leaves through a per-wave ring [16 rows][96 distances] (distance mod 96): the un-skewed values land
-    // here 2 bytes at a time and go to HBM as whole aligned 16-byte chunks, 8 per row and key tile (the chunks the
-    // tile completed) -- 2 store instructions per wave and tile instead of 20 two-byte ones.  16-byte chunk index XOR
-    // (row >> 2) keeps the four row groups of a write on different banks.
-    constexpr int SRING = 96;
-    __shared__ __attribute__((aligned(16))) bf16 sS[NW * 16 * SRING];
+    // dS-by-distance leaves through a per-wave ring [16 rows][128 distances] (distance mod 128, row pitch 136 elements:
+    // the four row groups of a write land 16 banks apart).  Element (row, jj) of a key tile IS distance
+    // d = i + M - j0 - jj: it is written straight to column d & 127 of its row -- the skew is absorbed by the LDS
+    // address (no permutes, no selects, no range checks; masked positions carry dS = 0) -- and leaves for HBM as whole
+    // aligned 16-byte chunks, 8 per row and key tile (the chunks the tile completed).
+    constexpr int SRING = 128, SPITCH = 136;
+    __shared__ __attribute__((aligned(16))) bf16 sS[NW * 16 * SPITCH];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
     const int QT = (a.T + QROWS - 1) / QROWS;
     const int QH = (QT + 1) / 2;          // query tiles q and QT-1-q back to back (see relattn_fwd_kernel)
     int qslot, h, b;
     tile_coords(QH, a.H, a.B, qslot, h, b);
-    bf16* myS = sS + w * 16 * SRING;
+    bf16* myS = sS + w * 16 * SPITCH;
     for (int rep = 0; rep < 2; ++rep) {
     const int qt = rep == 0 ? QT - 1 - qslot : qslot;
     if (rep == 1 && qt >= QT - 1 - qslot) break;
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
+    DropLane dl_;
+    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    const unsigned thr_hi = a.drop_thr << 16;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;
     const int HD = a.H * DH;
+    // dS = P (keep dP/(1-p) - delta) scale  =  [P scale/(1-p)] (keep dP - delta (1-p)): the constant factor goes into the
+    // exponent (lse2 below), delta is pre-multiplied per row -- per element: exp2, select, subtract, multiply
+    const float dsc = DROP ? a.drop_scale : 1.f;
 
     bf16x8 qu[KS], qv[KS], dof[KS];
     {
@@ -454,8 +762,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int i = min(i0 + 16 * w + 4 * g + reg, T - 1);
-        lse2[reg] = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E;
-        dl[reg] = a.delta[((size_t)b * a.H + h) * T + i];
+        lse2[reg] = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E - __log2f(a.scale * dsc);
+        dl[reg] = a.delta[((size_t)b * a.H + h) * T + i] / dsc;
         srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
         lower[reg] = r16 < 4 * g + reg;
     }
@@ -466,8 +774,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     int jt_lo, jt_hi;
     kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
     bf16* myD = sD + w * 64 * PT;
-#pragma unroll
-    for (int n = 0; n < 3; ++n) *(bf16x8*)(myS + (lane + 64 * n) * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = lane; n < 16 * SPITCH / 8; n += 64) *(bf16x8*)(myS + n * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 
     const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
     const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
@@ -542,55 +849,25 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
                     if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst) || i >= T) s[c][reg] = -INFINITY;
             }
         }
-        // dS = P (dP - delta) scale ; keep it in s[c][reg]
+        // dS = P (dP - delta) scale
+        const int dcol0 = iw_lo + 4 * g + M - j0 - r16;          // distance of (row 4g, jj = r16)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 db;
             unsigned hw[2] = {0u, 0u};
-            if (DROP) {
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp)
-                    hw[rp] = mix32(seed_bh + (unsigned)((iw_lo + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(j0 + 16 * c + r16));
-            }
+            if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);
+                const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);          // P * scale / (1-p)
                 float dpe = dp[c][reg];
-                if (DROP) dpe = (((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr) ? dpe * a.drop_scale : 0.f;
-                const float ds = p * (dpe - dl[reg]) * a.scale;
-                s[c][reg] = ds;
-                db[reg] = f2bf(ds);
+                if (DROP) dpe = drop_keep16(hw, reg, a.drop_thr, thr_hi) ? dpe : 0.f;
+                db[reg] = f2bf(p * (dpe - dl[reg]));
             }
             *(bf16x4*)(myD + pt_off(16 * c + r16, g)) = db;       // dS^T[kv][row]
-        }
-        // un-skew: dQR[row][b] = dS[row][jj = row + 63 - b]  ->  dSk[i][d = dlo_w + b]
-        const int dlo_w = i0 + M - j0 - 63 + 16 * w;
+            // by distance: (row 4g+reg, jj = 16c + r16) -> ring column (i + M - j0 - jj) & 127
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = 4 * g + reg;
-            const int i = iw_lo + row;
-            const float e0 = bperm(srcaddr[reg], s[0][reg]), e1 = bperm(srcaddr[reg], s[1][reg]),
-                        e2 = bperm(srcaddr[reg], s[2][reg]), e3 = bperm(srcaddr[reg], s[3][reg]);
-            // block blk takes c = 4-blk on lanes r16 < row, c = 3-blk elsewhere
-            const float v0 = lower[reg] ? 0.f : e3;
-            const float v1 = lower[reg] ? e3 : e2;
-            const float v2 = lower[reg] ? e2 : e1;
-            const float v3 = lower[reg] ? e1 : e0;
-            const float v4 = lower[reg] ? e0 : 0.f;
-            {
-                const int jj0 = row + 63 - r16;          // jj of block 0; block blk: jj0 - 16*blk
-                const int d0 = dlo_w + r16;
-                bf16* srow = myS + row * SRING;
-#define COMMU_DSK_STORE(BLK, VAL)                                                           \
-                {                                                                            \
-                    const int jj = jj0 - 16 * (BLK);                                         \
-                    const unsigned col = (unsigned)(d0 + 16 * (BLK) + 16 * SRING) % SRING;   \
-                    if (jj >= 0 && jj <= 63) srow[(((col >> 3) ^ g) << 3) | (col & 7)] = f2bf(VAL);          \
-                }
-                COMMU_DSK_STORE(0, v0) COMMU_DSK_STORE(1, v1) COMMU_DSK_STORE(2, v2) COMMU_DSK_STORE(3, v3)
-                COMMU_DSK_STORE(4, v4)
-#undef COMMU_DSK_STORE
-            }
+            for (int reg = 0; reg < 4; ++reg)
+                myS[(4 * g + reg) * SPITCH + ((dcol0 + reg - 16 * c) & (SRING - 1))] = db[reg];
         }
         __builtin_amdgcn_wave_barrier();
         // flush: row r (distance dl = i + M - j0 at jj = 0) completed the aligned chunks 8c in [dl - 63, dl]
@@ -601,8 +878,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
                 const int dl = i + M - j0;
                 const int c = ((dl - 56) >> 3) + (lane & 3) + 4 * n;          // ceil((dl - 63) / 8) + k
                 if (i < T && c >= 0 && 8 * c <= dl) {
-                    const unsigned col = (unsigned)(8 * c) % SRING;
-                    const bf16x8 v8 = *(const bf16x8*)(myS + row * SRING + (((col >> 3) ^ (row >> 2)) << 3));
+                    const bf16x8 v8 = *(const bf16x8*)(myS + row * SPITCH + ((8 * c) & (SRING - 1)));
                     const size_t m = (size_t)i * B + b;
                     bf16* dst;
                     if (a.dsk_tiled)
@@ -684,7 +960,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
     __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
     __shared__ __attribute__((aligned(16))) float sLse[64], sDl[64];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
     const int NT = (a.T + a.M + KCOLS - 1) / KCOLS, NH = (NT + 1) / 2;      // key tiles j and NT-1-j back to back
     int jslot, h, b;
     tile_coords(NH, a.H, a.B, jslot, h, b);
@@ -693,8 +969,15 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
     if (rep == 1 && jt <= jslot) break;
     const int j0 = jt * KCOLS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    const unsigned seed_bh = a.drop_seed + (unsigned)(b * a.H + h) * 0x9E3779B1u;
+    DropLane dl_;
+    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    const unsigned thr_hi = a.drop_thr << 16;
     const int HD = a.H * DH;
+    // With P' = P ln2/(1-p) (the factor goes into the exponent through sLse):  dS'' = P' (keep dP - delta (1-p))  and
+    // dV = [sum keep P' dO] / ln2 (applied to the accumulator at the end) -- per element: exp2, two selects, subtract,
+    // multiply; (q+u) is pre-scaled by scale*log2e, hence the ln2
+    const float dsc = DROP ? a.drop_scale : 1.f;
+    const float lse_shift = __log2f(LN2 * dsc);
 
     bf16x8 kf[KS], vf[KS];
     {
@@ -744,8 +1027,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
         stR.load(srdR, (unsigned)(dlo + 64 * half) * rdb);
         if (tid < 64) {
             const int i = min(i0 + tid, T - 1);
-            plse = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E;
-            pdl = a.delta[((size_t)b * a.H + h) * T + i];
+            plse = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E - lse_shift;
+            pdl = a.delta[((size_t)b * a.H + h) * T + i] / dsc;
         }
     };
     auto commit = [&](bf16* rdst) {
@@ -790,11 +1073,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                 qr1 = mfma16(qvf, frag<DH>(sR, pr1, 4 * ks + g), qr1);
             }
             unsigned hw[2] = {0u, 0u};
-            if (DROP) {
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp)
-                    hw[rp] = mix32(seed_bh + (unsigned)((i0 + 16 * rb + 4 * g + 2 * rp) >> 1) * (unsigned)K + (unsigned)(jw_lo + r16));
-            }
+            if (DROP) dl_.words((i0 >> 4) + rb, jw_lo >> 4, hw);
             const f32x4 lse4 = *(const f32x4*)&sLse[16 * rb + 4 * g], dl4 = *(const f32x4*)&sDl[16 * rb + 4 * g];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
@@ -804,15 +1083,15 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                 float sc = s[reg] + (lower[reg] ? p1 : p0);
                 if (need_mask && (is_masked(i0 + ii, jw_lo + r16, M, a.same_length, a.sshift, rst) || i0 + ii >= T))
                     sc = -INFINITY;
-                const float p = __builtin_amdgcn_exp2f(sc - lse4[reg]);
+                const float p = __builtin_amdgcn_exp2f(sc - lse4[reg]);          // P' = P ln2 / (1-p)
                 float pd = p, dpe = dp[reg];
                 if (DROP) {
-                    const bool keep = ((hw[reg >> 1] >> (16 * (reg & 1))) & 0xFFFFu) >= a.drop_thr;
-                    pd = keep ? p * a.drop_scale : 0.f;
-                    dpe = keep ? dpe * a.drop_scale : 0.f;
+                    const bool keep = drop_keep16(hw, reg, a.drop_thr, thr_hi);
+                    pd = keep ? p : 0.f;
+                    dpe = keep ? dpe : 0.f;
                 }
                 pb[rb][reg] = f2bf(pd);
-                dsb[rb][reg] = f2bf(p * (dpe - dl4[reg]) * LN2);           // (q+u) is pre-scaled: scale/c2 = ln2
+                dsb[rb][reg] = f2bf(p * (dpe - dl4[reg]));
             }
         }
         // dv += P^T dO ; dk += dS''^T qu2: k-slots e<4 -> ii = 32pp+4g+e, e>=4 -> ii = 32pp+16+4g+e-4
@@ -842,7 +1121,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
                 a.dk[off + 16 * d + r16] = f2bf(dk[d][reg]);
-                a.dv[off + 16 * d + r16] = f2bf(dv[d][reg]);
+                a.dv[off + 16 * d + r16] = f2bf(dv[d][reg] * (1.f / LN2));
             }
         }
     }
@@ -935,6 +1214,14 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     // tiles at every shape of this model, so only NW = 4 is instantiated)
     dim3 grid((((d->T + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
+    static const int fwd_gen = getenv("COMMU_ATTN_FWD_GEN") ? atoi(getenv("COMMU_ATTN_FWD_GEN")) : 2;
+    if (d->DH == 64 && fwd_gen == 2) {          // second-generation kernel: 128 query rows per workgroup
+        dim3 grid2((((d->T + 127) / 128 + 1) / 2) * d->H * d->B);
+        if (drop) COMMU_LAUNCH((relattn_fwd2_kernel<true>), grid2, dim3(512), 0, stream, a);
+        else COMMU_LAUNCH((relattn_fwd2_kernel<false>), grid2, dim3(512), 0, stream, a);
+        COMMU_LAUNCH_CHECK();
+        return 0;
+    }
 #define ATTN_FWD(DHV)                                                                              \
     {                                                                                              \
         if (drop) COMMU_LAUNCH((relattn_fwd_kernel<DHV, 4, true>), grid, dim3(256), 0, stream, a); \

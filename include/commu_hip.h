@@ -86,6 +86,11 @@ int commu_gemm_tn_bf16_grouped(const commu_tn_problem* probs, int nprob, int M, 
 /* dst[z][r*ldd + c] = (accumulate ? dst : 0) + alpha * sum_s src[(z*nslabs + s)*stride + r*cols + c] */
 int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, const float* src, int rows, int cols,
                              int nslabs, size_t stride, int batch, int accumulate, float alpha, hipStream_t stream);
+/* cropping form for zero-padded models (d_head 50 -> 64 ...): the slabs hold the padded [rg*rp, cg*cp] product, its
+ * [rt, ct] blocks go to dst [rg*rt, cg*ct]:
+ *   dst[((a*rt + r)*cg + c)*ct + k] (+)= alpha * sum_s src[s*stride + ((a*rp + r)*cg + c)*cp + k] */
+int commu_reduce_slabs_crop_f32(float* dst, const float* src, int rg, int rt, int rp, int cg, int ct, int cp,
+                                int nslabs, size_t stride, int accumulate, float alpha, hipStream_t stream);
 /* dst[i] = (accumulate ? dst[i] : 0) + alpha * sum_s src[s*stride + i] */
 int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, size_t stride,
                            int accumulate, float alpha, hipStream_t stream);
@@ -95,8 +100,11 @@ int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, s
  * on input, written as zeros on output, so the next GEMM can contract over the padded width (d_model 500 -> 512). */
 /* ---- embedding (AdaptiveEmbedding.forward, model.py:409-420) and its gradient */
 /* (drop_p > 0: dropout of the scaled embedding, `core_out = self.drop(word_emb)`, model.py:585;
- *  every dropout in this ABI is the counter-based mask keep(seed, element index)) */
-int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo, int ntok, int D,
+ *  every dropout in this ABI is the counter-based mask keep(seed, element index): a 32-bit integer hash of the
+ *  index, KEYED by the seed between its two multiply rounds -- see common.cuh drop_keep and DESIGN.md) */
+/* (a token id outside [0, V) -- the reference raises IndexError -- yields a NaN row, hence a NaN loss; likewise
+ *  commu_ce_fwd returns NaN for a target outside [0, V): no out-of-bounds access, no silent garbage) */
+int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo, int ntok, int D, int V,
                     float scale, unsigned drop_seed, float drop_p, hipStream_t stream);
 int commu_embed_bwd(const int64_t* tok, const void* dX_bf16, int ldx, float* dE, int ntok, int D, int V,
                     float scale, int accumulate, unsigned drop_seed, float drop_p, hipStream_t stream);
@@ -149,6 +157,14 @@ int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, 
 int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
                              hipStream_t stream);
 int commu_copy_bf16(const void* src, void* dst, size_t n, hipStream_t stream);
+
+/* K9  memory update (reference commu/model/model.py:507-538 _update_mems): for each of `layers` layers
+ *   out[l] = [ mems[l][mem_skip : mem_skip+keep) ; hids[l][hid_skip : hid_skip+take) ]
+ * all counts/strides in bf16 ELEMENTS and multiples of 8 (a time step is a whole [B, Dp] slab); one launch.
+ * -22 on a misaligned count or a missing pointer. */
+int commu_mems_update(const void* hids, size_t hid_stride, size_t hid_skip, size_t take, const void* mems,
+                      size_t mem_stride, size_t mem_skip, size_t keep, void* out, size_t out_stride, int layers,
+                      hipStream_t stream);
 
 /* ---- relative-position attention with XL memory
  * (RelPartialLearnableMultiHeadAttn.forward, model.py:313-345; _rel_shift :251-259; mask :549-574) */

@@ -14,6 +14,7 @@ M = int(os.environ.get("AB_M", 0))
 H, DH = 8, 64
 REPS = int(os.environ.get("AB_REPS", 3))
 WHAT = os.environ.get("AB_WHAT", "fwd,bwd")
+DROP = float(os.environ.get("AB_DROP", 0.0))
 dev = "cuda"
 K = T + M
 HD = H * DH
@@ -30,10 +31,10 @@ du, dvb = torch.zeros(HD, device=dev), torch.zeros(HD, device=dev)
 
 
 def run():
-    out, lse, qs = ops.relattn_fwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, save_q=True)
+    out, lse, qs = ops.relattn_fwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, save_q=True, drop_p=DROP, drop_seed=1234)
     if "bwd" in WHAT:
         ops.relattn_bwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, out, dout, lse, qs, dqkv[M * B:, :HD],
-                        dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+                        dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=DROP, drop_seed=1234)
 
 
 run()

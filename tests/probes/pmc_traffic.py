@@ -1,6 +1,8 @@
 """FETCH_SIZE / WRITE_SIZE (KiB) per launch of the attention kernels -> bytes per launch (JSON for bench.py).
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-byte requests at 64 bytes -> x2."""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
@@ -25,8 +27,13 @@ def per_launch(db, counter):
 
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
-out = {"shape": [6, 512, 8, 1024, 0, 64], "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-       "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB",
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sha = hashlib.sha256()
+for name in ("relattn.hip", "common.cuh"):          # the same hash bench.py computes: a stale profile is refused
+    with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
+        sha.update(f.read())
+out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": sha.hexdigest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+       "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-extra`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB",
        "fetch_kib_raw": {KERNELS[k]: fetch.get(k) for k in KERNELS}, "write_kib_raw": {KERNELS[k]: write.get(k) for k in KERNELS},
        "bytes_per_launch": {KERNELS[k]: (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in KERNELS}}
 json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -3,6 +3,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 out=gpurun_out/prof_attn
+echo "AB_DROP=${AB_DROP:-0}"
 rm -rf $out; mkdir -p $out
 AB_B=64 AB_REPS=5 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 tests/probes/attn_bench.py > $out/log.txt 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)

@@ -40,6 +40,12 @@ def test_mask_statistics_and_determinism():
         agree = float((m == m2).float().mean())
         assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 3e-3          # independent sites
     assert ops.site_seed(5, 1) != ops.site_seed(5, 2) != ops.site_seed(6, 1)
+    # keyed hash: seeds that differ by a small integer must not give shifted copies of one mask
+    a = ops.dropout_keep_mask(1000, n, 0.5)
+    for d in (1, 2, 64, 4096):
+        b = ops.dropout_keep_mask(1000 + d, n, 0.5)
+        assert abs(float((a[d:] == b[:n - d]).float().mean()) - 0.5) < 5e-3, d
+        assert abs(float((a == b).float().mean()) - 0.5) < 5e-3, d
 
 
 def test_gemm_epilogue_dropout_exact_mask():

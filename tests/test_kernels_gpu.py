@@ -246,6 +246,58 @@ def test_embed_fwd_bwd():
     assert relerr(dE, ref) < 1e-5
 
 
+def test_out_of_range_ids_poison_the_loss():
+    """A token / target id outside [0, V) (the reference raises IndexError) must neither read out of bounds nor
+    pass silently: the embedding row and the row's nll come out NaN, the other rows are untouched."""
+    o = ops()
+    V, D, n = 729, 128, 64
+    E = rnd(V, D, seed=10)
+    tok = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(11))
+    bad = tok.clone()
+    bad[3], bad[17] = V, -1
+    out = o.embed_fwd(bad.to(DEV), E.to(DEV)).float().cpu()
+    ref = o.embed_fwd(tok.to(DEV), E.to(DEV)).float().cpu()
+    good = torch.ones(n, dtype=torch.bool)
+    good[3] = good[17] = False
+    assert torch.isnan(out[~good]).all() and torch.equal(out[good], ref[good])
+    logits = bf(rnd(n, 736, seed=12)).to(DEV)
+    nll, _ = o.ce_fwd(logits, bad.to(DEV), V)
+    nll_ref, _ = o.ce_fwd(logits, tok.to(DEV), V)
+    assert torch.isnan(nll.cpu()[~good]).all() and torch.equal(nll.cpu()[good], nll_ref.cpu()[good])
+
+
+@pytest.mark.parametrize("T,M,mem_len", [(4, 10, 10), (4, 10, 6), (7, 3, 9), (5, 0, 3)])
+def test_mems_update_kernel(T, M, mem_len):
+    """K9 against torch.cat(...)[beg:end] (model.py:507-538), including a memory tensor that is a strided view."""
+    o = ops()
+    Lp, B, Dp = 3, 5, 64
+    hids = bf(rnd(Lp, T * B, Dp, seed=1)).to(DEV)
+    big = bf(rnd(Lp, M + 2, B, Dp, seed=2)).to(DEV)
+    mems = big[:, 2:]                                       # layer stride != M*B*Dp
+    end = M + T
+    beg = max(0, end - mem_len)
+    ref = torch.cat([mems, hids.view(Lp, T, B, Dp)], 1)[:, beg:end]
+    if beg >= M:
+        pytest.skip("no copy in this case: the model returns a view of the hidden-state buffer")
+    out = torch.full((Lp, end - beg, B, Dp), 7.0, device=DEV, dtype=torch.bfloat16)
+    o.mems_update(hids, mems, out, beg)
+    assert torch.equal(out, ref)
+
+
+def test_reduce_slabs_crop():
+    o = ops()
+    rg, rt, rp, cg, ct, cp, ns = 6, 50, 64, 2, 100, 128, 3
+    stride = rg * rp * cg * cp + 40
+    slabs = rnd(ns, stride, seed=3).to(DEV)
+    full = slabs[:, :rg * rp * cg * cp].sum(0).view(rg, rp, cg, cp)[:, :rt, :, :ct].reshape(rg * rt, cg * ct)
+    dst = rnd(rg * rt, cg * ct, seed=4).to(DEV)
+    want = dst + full
+    o.reduce_slabs_crop(dst, slabs, (rg, rt, rp, cg, ct, cp), ns, stride, True)
+    assert float((dst - want).abs().max()) < 1e-5
+    o.reduce_slabs_crop(dst, slabs, (rg, rt, rp, cg, ct, cp), ns, stride, False)
+    assert float((dst - full).abs().max()) < 1e-5
+
+
 def test_posemb_distance_order():
     o = ops()
     K, D = 37, 64
