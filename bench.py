@@ -296,7 +296,11 @@ def extra_rows(args, dev):
     rows = {}
     for tag, over in EXTRA_ROWS:
         a = argparse.Namespace(**{**vars(args), **over})
-        steps, warmup = 4, 2
+        # warm-up until the XL memory has reached its full length (tgt_len 128 / mem_len 1024: nine segments), so that
+        # the timed steps run at the steady-state shapes
+        steps, warmup = 5, max(3, a.mem_len // a.tgt_len + 2)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         elapsed, tps, prof = train_bench(a, dev, 1, 0, steps, warmup)
         f = 3.0 * fwd_flops_per_token(a.layers, a.d_model, a.d_inner, a.tgt_len, a.mem_len) * tps
         rows[tag] = {"value": round(tps * steps / elapsed, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * elapsed / steps, 3),

@@ -28,7 +28,7 @@ class AttnDesc(C.Structure):
 class AttnBwdDesc(C.Structure):
     _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
                 ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
-                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i)]
+                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i), ("p_scratch", c_p)]
 
 
 class TnProblem(C.Structure):
@@ -73,6 +73,7 @@ PROTOTYPES = {
     "commu_copy_bf16": [c_p, c_p, c_z, c_p],
     "commu_mems_update": [c_p, c_z, c_z, c_z, c_p, c_z, c_z, c_z, c_p, c_z, c_i, c_p],
     "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p],
+    "commu_attn_p_scratch_elems": [c_i, c_i, c_i, c_i],
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_q": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_kv": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
@@ -91,9 +92,9 @@ PROTOTYPES = {
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_hip_version": [],
 }
-_RESTYPE = {"commu_hip_version": C.c_char_p}
+_RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong}
 _NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
-            "commu_forcing_state_ints"}
+            "commu_forcing_state_ints", "commu_attn_p_scratch_elems"}
 
 _lib = None
 

@@ -436,6 +436,7 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 # D512): 0.324 ms / step fused vs 0.293 ms with the separate LayerNorm kernel -- the two LDS reductions and the
 # normalisation arithmetic cost a latency-bound skinny GEMM more than the launch they save -- so it is OFF by default.
 FUSE_DECODE_LN = False
+STORE_ATTN_P = True         # backward: bwd_q stores P for bwd_kv (d_head 64); False: both kernels recompute it
 NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead of commu_relattn_bwd_band
 
 
@@ -488,6 +489,20 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     e.dsk, e.du_part = dsk.data_ptr(), du_part.data_ptr()
     e.ld_dqkv, e.ld_dsk, e.du_rows, e.dsk_wedge = dk.stride(0), ld_dsk, QT, wedge
     e.dsk_tiled = 1 if band_slabs else 0
+    pscr = None
+    if DH == 64 and STORE_ATTN_P:
+        # the query-stationary kernel stores the probabilities it recomputes, the key-stationary one reads them back
+        n = call("commu_attn_p_scratch_elems", T, M, B, H)
+        if scratch is not None and not POISON_SCRATCH:
+            if scratch.get("p") is None or scratch["p"].numel() < n:
+                scratch["p"] = None
+                scratch["p"] = torch.empty(n, device=dev, dtype=BF16)
+            pscr = scratch["p"]
+        else:
+            pscr = torch.empty(n, device=dev, dtype=BF16)
+            if POISON_SCRATCH:
+                pscr.fill_(float("nan"))
+        e.p_scratch = pscr.data_ptr()
     import os as _os
     if _os.environ.get("COMMU_ABL_DSK"):          # profiling ablation: bwd_q without its dS-by-distance stores
         e.dsk_wedge = -7

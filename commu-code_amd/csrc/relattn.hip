@@ -48,6 +48,7 @@ struct AttnArgs {
     bf16* dv;
     bf16* dsk;          // [H][T*B][ld_dsk]  dS indexed by distance d (zero-initialised by the caller)
     float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
+    bf16* pbuf;         // P scratch [B*H][ceil(T/16)][ceil(K/64)][64 keys][16 rows]: written by bwd_q, read by bwd_kv2 (or null)
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
     int dsk_wedge;      // > 0: dsk is uninitialised; zero columns i+M+1 .. i+M+dsk_wedge of every row (band GEMM contract)
     int dsk_tiled;      // != 0: dsk is stored as [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (band.hip)
@@ -481,6 +482,8 @@ __device__ __forceinline__ void lds_dma16(srd_t srd, unsigned voff, unsigned lds
                  :: "s"(lds_dst), "v"(voff), "s"(srd) : "memory");
 }
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <bool DROP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void relattn_fwd2_kernel(const AttnArgs a) {
@@ -525,6 +528,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         lower[reg] = r16 < 4 * g + reg;
     }
     bf16* const myP = sP + w * 64 * PT;
+    // LDS addressing is spelled out as (lane constant) + (wave-uniform base) + (immediate), in bytes: hipcc otherwise
+    // hoists one address register per (k-step, half, feature block) of the transpose reads -- two dozen registers that
+    // end up in scratch under the 128-register budget.
+    const LDS_AS char* const lds = (const LDS_AS char*)smem;
+    //  V^T operand (ds_read_b64_tr_b16 from the row-major tile): rows 32ks + 8g + 4half + (r16 >> 2), features
+    //  16d + 4(r16 & 3).  Row, swizzled 16-byte chunk and byte-in-chunk occupy disjoint bit fields of the address and the
+    //  feature block d only enters the chunk as (2d) ^ ..., so address(half, d) = vo[half] ^ (32 d): two constants;
+    //  k-step ks is +4096 bytes.
+    int vo[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int row = 8 * g + 4 * hf + (r16 >> 2), col = 4 * (r16 & 3);
+        vo[hf] = row * 128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7) * 2;
+    }
+    //  P^T image of the wave (pitch PT, slot swizzle (k >> 2) & 3 = (2g + half) & 3): k-step ks is +1024 bytes
+    int po[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) po[hf] = pt_off(8 * g + 4 * hf + (r16 >> 2), r16 & 3) * 2;
+    const int pbase = (8 * TILE + w * 64 * PT) * 2;          // the wave's P buffer
+    auto tr8 = [&](int byte_off) {
+        return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(lds + byte_off)));
+    };
 
     for (int rep = 0; rep < 2; ++rep) {
     const int qt = rep == 0 ? QT - 1 - qslot : qslot;
@@ -583,32 +608,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (jt < jt_hi) stage(jt + 1, t + 1, 0);
         // a wave whose 16 rows see nothing of this key tile only takes part in the staging
         if (j0 > iw_hi + M || (a.same_length && j0 + 63 <= iw_lo - a.sshift) || iw_lo >= T) continue;
-        const bf16* tK = sK + (t & 1) * TILE;
-        const bf16* tV = sV + (t & 1) * TILE;
+        const int kb = (t & 1) * (TILE * 2), vb = 2 * TILE * 2 + kb;          // byte bases of this tile's K and V buffers
 
-        f32x4 qr[5];
-#pragma unroll
-        for (int blk = 0; blk < 5; ++blk) {
-            qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // band product, one 16-distance block at a time from the top: block pair (4-c, 3-c) gives the skewed diagonal of
+        // score block c, BD[row][jj] = QR[row][row - jj + 63] -- the INITIAL value of its accumulator -- so only two band
+        // blocks are live at any time
+        auto band = [&](int blk) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
             const int x = 16 * w + 16 * blk;                  // band row of the block; chunk x >> 6 sits in slot (chunk - t) & 3
-            const bf16* rb = sR + ((((x >> 6) - t) & 3) * 64 + (x & 63)) * DH;
+            const int rb = (4 * TILE + ((((x >> 6) - t) & 3) * 64 + (x & 63)) * DH) * 2;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], ld_bf16x8(rb + foff[ks]), qr[blk]);
-        }
+            for (int ks = 0; ks < KS; ++ks) r = mfma16(qv[ks], *(const LDS_AS bf16x8*)(lds + rb + 2 * foff[ks]), r);
+            return r;
+        };
+        auto skew = [&](const f32x4& hi, const f32x4& lo) {          // select at the SOURCE lane, then one permute per output
+            f32x4 r;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) r[reg] = bperm(srcaddr[reg], lower[reg] ? hi[reg] : lo[reg]);
+            return r;
+        };
         f32x4 s[4];
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
-                        t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
-            s[0][reg] = bperm(srcaddr[reg], t0);
-            s[1][reg] = bperm(srcaddr[reg], t1);
-            s[2][reg] = bperm(srcaddr[reg], t2);
-            s[3][reg] = bperm(srcaddr[reg], t3);
+        {
+            f32x4 qa = band(4), qb = band(3);
+            s[0] = skew(qa, qb);
+            qa = band(2);
+            s[1] = skew(qb, qa);
+            qb = band(1);
+            s[2] = skew(qa, qb);
+            qa = band(0);
+            s[3] = skew(qb, qa);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[c] = mfma16(qu[ks], ld_bf16x8(tK + 16 * c * DH + foff[ks]), s[c]);
+            for (int ks = 0; ks < KS; ++ks) s[c] = mfma16(qu[ks], *(const LDS_AS bf16x8*)(lds + kb + 2 * foff[ks] + 2048 * c), s[c]);
         }
         const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
                                (rst && j0 < M) || (iw_hi >= T);
@@ -669,10 +702,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         //  was measured: the extra live registers cost more than the exposed LDS latency at four waves per SIMD)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pf = frag_tr(myP, 32 * ks, r16, g);
+            bf16x8 pf;
+            {
+                const bf16x4 lo = tr8(pbase + po[0] + 1024 * ks), hi = tr8(pbase + po[1] + 1024 * ks);
+                pf[0] = lo[0]; pf[1] = lo[1]; pf[2] = lo[2]; pf[3] = lo[3]; pf[4] = hi[0]; pf[5] = hi[1]; pf[6] = hi[2]; pf[7] = hi[3];
+            }
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-                o[d] = mfma16(pf, frag_tr_rm<DH>(tV, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, 16 * d, r16), o[d]);
+            for (int d = 0; d < DB; ++d) {
+                const bf16x4 lo = tr8(((vb + vo[0]) ^ (32 * d)) + 4096 * ks), hi = tr8(((vb + vo[1]) ^ (32 * d)) + 4096 * ks);
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3]; vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                o[d] = mfma16(pf, vf, o[d]);
+            }
         }
         __builtin_amdgcn_wave_barrier();                         // P image is rewritten by the next tile
     }
@@ -767,6 +808,14 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
         lower[reg] = r16 < 4 * g + reg;
     }
+    // P scratch for relattn_bwd_kv2_kernel: this (batch, head)'s [ceil(T/16)][ceil(K/64)] blocks of 2 KB
+    const int JT = (K + 63) >> 6;
+    const bool pstore = a.pbuf != nullptr && i0 + 16 * w < T;
+    const srd_t srdP = make_srd(a.pbuf + ((size_t)b * a.H + h) * ((T + 15) >> 4) * JT * 1024, (size_t)((T + 15) >> 4) * JT * 2048);
+    const int pvoff = pt_off(r16, g) * 2;          // bytes; pt_off(16c + r16, g) = 256 c + pt_off(r16, g)
+    int foff[KS];          // fragment addressing: lane part r16 * DH + swizzled chunk (block rows are multiples of 16)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r16 * DH + (((4 * ks + g) ^ (swz<DH>(r16) & (DH / 8 - 1))) << 3);
     f32x4 dq[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -816,17 +865,17 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             s[c] = dp[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s[c] = mfma16(qu[ks], frag<DH>(sK, 16 * c + r16, 4 * ks + g), s[c]);
-                dp[c] = mfma16(dof[ks], frag<DH>(sV, 16 * c + r16, 4 * ks + g), dp[c]);
+                s[c] = mfma16(qu[ks], ld_bf16x8(sK + 16 * c * DH + foff[ks]), s[c]);
+                dp[c] = mfma16(dof[ks], ld_bf16x8(sV + 16 * c * DH + foff[ks]), dp[c]);
             }
         }
         f32x4 qr[5];
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int prow = ring_row<NCH, NCH - 1>(16 * w + 16 * blk, t) + r16;
+            const bf16* rb = sR + ring_row<NCH, NCH - 1>(16 * w + 16 * blk, t) * DH;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], frag<DH>(sR, prow, 4 * ks + g), qr[blk]);
+            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], ld_bf16x8(rb + foff[ks]), qr[blk]);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -856,13 +905,19 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             bf16x4 db;
             unsigned hw[2] = {0u, 0u};
             if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
+            bf16x4 pq;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);          // P * scale / (1-p)
                 float dpe = dp[c][reg];
                 if (DROP) dpe = drop_keep16(hw, reg, a.drop_thr, thr_hi) ? dpe : 0.f;
                 db[reg] = f2bf(p * (dpe - dl[reg]));
+                pq[reg] = f2bf(p);
             }
+            // the key-stationary kernel re-reads P instead of recomputing it (block of 16 rows x 64 keys, P^T image order)
+            if (DH == 64 && pstore)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), srdP, pvoff + 512 * c,
+                                                      (((iw_lo >> 4) * JT + jt) << 11), 0);
             *(bf16x4*)(myD + pt_off(16 * c + r16, g)) = db;       // dS^T[kv][row]
             // by distance: (row 4g+reg, jj = 16c + r16) -> ring column (i + M - j0 - jj) & 127
 #pragma unroll
@@ -997,6 +1052,11 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
         srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
         lower[reg] = r16 < 4 * g + reg;
     }
+    // fragment addressing (elements): lane part r16 * DH + swizzled 16-byte chunk (block rows are multiples of 16, so
+    // row & 7 == r16 & 7); the block's row offset is wave-uniform and mostly an immediate
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r16 * DH + (((4 * ks + g) ^ (swz<DH>(r16) & (DH / 8 - 1))) << 3);
     f32x4 dk[DB], dv[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) dk[d] = dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1063,27 +1123,33 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             f32x4 qr0 = {0.f, 0.f, 0.f, 0.f}, qr1 = {0.f, 0.f, 0.f, 0.f};
             const int base = 16 * (rb - w + NW - 1);      // band rows base .. base+31
-            const int pr0 = ring_row<NCH, 1>(base, t) + r16, pr1 = ring_row<NCH, 1>(base + 16, t) + r16;
+            const bf16* r0 = sR + ring_row<NCH, 1>(base, t) * DH;
+            const bf16* r1 = sR + ring_row<NCH, 1>(base + 16, t) * DH;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qvf = frag<DH>(sQv, 16 * rb + r16, 4 * ks + g);
-                s = mfma16(frag<DH>(sQu, 16 * rb + r16, 4 * ks + g), kf[ks], s);
-                dp = mfma16(frag<DH>(sdO, 16 * rb + r16, 4 * ks + g), vf[ks], dp);
-                qr0 = mfma16(qvf, frag<DH>(sR, pr0, 4 * ks + g), qr0);
-                qr1 = mfma16(qvf, frag<DH>(sR, pr1, 4 * ks + g), qr1);
+                const bf16x8 qvf = ld_bf16x8(sQv + 16 * rb * DH + foff[ks]);
+                s = mfma16(ld_bf16x8(sQu + 16 * rb * DH + foff[ks]), kf[ks], s);
+                dp = mfma16(ld_bf16x8(sdO + 16 * rb * DH + foff[ks]), vf[ks], dp);
+                qr0 = mfma16(qvf, ld_bf16x8(r0 + foff[ks]), qr0);
+                qr1 = mfma16(qvf, ld_bf16x8(r1 + foff[ks]), qr1);
             }
             unsigned hw[2] = {0u, 0u};
             if (DROP) dl_.words((i0 >> 4) + rb, jw_lo >> 4, hw);
             const f32x4 lse4 = *(const f32x4*)&sLse[16 * rb + 4 * g], dl4 = *(const f32x4*)&sDl[16 * rb + 4 * g];
+            // skewed band term: block select at the SOURCE lane (dest lane s < row  <=>  source lane t < row), one permute
+            float sc[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) sc[reg] = s[reg] + bperm(srcaddr[reg], lower[reg] ? qr1[reg] : qr0[reg]);
+            if (need_mask) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int ii = 16 * rb + 4 * g + reg;
+                    if (is_masked(i0 + ii, jw_lo + r16, M, a.same_length, a.sshift, rst) || i0 + ii >= T) sc[reg] = -INFINITY;
+                }
+            }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p0 = bperm(srcaddr[reg], qr0[reg]);
-                const float p1 = bperm(srcaddr[reg], qr1[reg]);
-                const int ii = 16 * rb + 4 * g + reg;
-                float sc = s[reg] + (lower[reg] ? p1 : p0);
-                if (need_mask && (is_masked(i0 + ii, jw_lo + r16, M, a.same_length, a.sshift, rst) || i0 + ii >= T))
-                    sc = -INFINITY;
-                const float p = __builtin_amdgcn_exp2f(sc - lse4[reg]);          // P' = P ln2 / (1-p)
+                const float p = __builtin_amdgcn_exp2f(sc[reg] - lse4[reg]);          // P' = P ln2 / (1-p)
                 float pd = p, dpe = dp[reg];
                 if (DROP) {
                     const bool keep = drop_keep16(hw, reg, a.drop_thr, thr_hi);
@@ -1116,6 +1182,158 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int j = j0 + 16 * w + 4 * g + reg;
+        if (j < K) {
+            const size_t off = ((size_t)j * B + b) * a.ld_dqkv + h * DH;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                a.dk[off + 16 * d + r16] = f2bf(dk[d][reg]);
+                a.dv[off + 16 * d + r16] = f2bf(dv[d][reg] * (1.f / LN2));
+            }
+        }
+    }
+    __syncthreads();
+    }
+}
+
+// =============================================================================================
+// Key-stationary backward from STORED probabilities (d_head 64).  The query-stationary kernel above recomputes
+// P scale/(1-p) anyway; when the caller provides a scratch buffer it also writes it out (bf16, 2 KB per block of 16 rows
+// x 64 keys, the lane order of the P^T image), and this kernel -- launched after it -- reads it back instead of
+// recomputing (q+u).k, the band product with its skew, the masks and the exponentials: what remains is dP = dO.V^T,
+// dS'' and the two products that consume P and dS''.  (Keeping the probabilities from the FORWARD pass was built and
+// measured too: the 128-register forward kernel pays more for the extra stores than both backward kernels gain.)
+// key-stationary: dk, dv (as relattn_bwd_kv_kernel: wave w owns key columns 16w..16w+15 of the 64-column tile).
+template <bool DROP>
+__global__ __launch_bounds__(256) void relattn_bwd_kv2_kernel(const AttnArgs a) {
+    constexpr int DH = 64, NW = 4, KS = 2, DB = 4, KCOLS = 64, NTHR = 256;
+    __shared__ __attribute__((aligned(16))) bf16 sQu[64 * DH];
+    __shared__ __attribute__((aligned(16))) bf16 sdO[64 * DH];
+    __shared__ __attribute__((aligned(16))) float sRs[64], sDl[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+    const int T = a.T, M = a.M, B = a.B, K = T + M, HD = a.H * DH;
+    const int NT = (K + KCOLS - 1) / KCOLS, NH = (NT + 1) / 2;      // key tiles j and NT-1-j back to back
+    const int IB = (T + 15) >> 4, JT = (K + 63) >> 6;
+    int jslot, h, b;
+    tile_coords(NH, a.H, B, jslot, h, b);
+    const bool rst = a.reset != nullptr && a.reset[b] != 0;
+    DropLane dl_;
+    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    const unsigned thr_hi = a.drop_thr << 16;
+    // P' = P ln2/(1-p):  dS'' = P' (keep dP - delta (1-p)),  dV = [sum keep P' dO] / ln2   (see relattn_bwd_kv_kernel);
+    // stored is P scale/(1-p)
+    const float dsc = DROP ? a.drop_scale : 1.f;
+    const float pmul = LN2 / a.scale;
+    int foff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = r16 * DH + (((4 * ks + g) ^ (r16 & 7)) << 3);
+    const unsigned qsb = (unsigned)B * HD * 2u, osb = (unsigned)B * a.ld_o * 2u;
+    const srd_t srdQu = make_srd(a.qu2 + (size_t)b * HD + h * DH, ((size_t)(T - 1) * B * HD + DH) * 2);
+    const srd_t srdO = make_srd(a.dout + (size_t)b * a.ld_o + h * DH, ((size_t)(T - 1) * B * a.ld_o + DH) * 2);
+    Stager<64, DH, NTHR> stQu, stO;
+    stQu.init(qsb, tid);
+    stO.init(osb, tid);
+    const size_t bh = (size_t)b * a.H + h;
+
+    for (int rep = 0; rep < 2; ++rep) {
+    const int jt = rep == 0 ? jslot : NT - 1 - jslot;
+    if (rep == 1 && jt <= jslot) break;
+    const int j0 = jt * KCOLS, jw_lo = j0 + 16 * w;
+    bf16x8 vf[KS];
+    {
+        const int j = jw_lo + r16;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const size_t off = ((size_t)min(j, K - 1) * B + b) * a.ld_qkv + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) vf[ks] = (j < K) ? ld_bf16x8(a.v + off + 32 * ks + 8 * g) : z;
+    }
+    f32x4 dk[DB], dv[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) dk[d] = dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // query tiles that see this kv tile: i >= j - M ; same_length: i < j + sshift
+    int it_lo = max(0, j0 - M) >> 6;
+    int it_hi = (T - 1) >> 6;
+    if (a.same_length) it_hi = min(it_hi, (j0 + KCOLS - 1 + a.sshift - 1) >> 6);
+    if (rst && j0 + KCOLS - 1 < M) it_hi = -1;          // whole tile is reset memory: no gradient
+    if (it_hi < it_lo) it_hi = it_lo - 1;
+
+    const bf16* pcol = a.pbuf + bh * IB * JT * 1024 + (size_t)jt * 1024 + pt_off(16 * w + r16, g);
+    float prs = 0.f, pdl = 0.f;
+    bf16x4 pun[4];
+    auto issue = [&](int it) {
+        const int i0 = it * 64;
+        stQu.load(srdQu, (unsigned)i0 * qsb);
+        stO.load(srdO, (unsigned)i0 * osb);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)          // rows beyond the last 16-row block: clamp (their row scale is 0)
+            pun[rb] = *(const bf16x4*)(pcol + (size_t)min((i0 >> 4) + rb, IB - 1) * JT * 1024);
+        if (tid < 64) {
+            const int i = i0 + tid;
+            prs = i < T ? pmul : 0.f;          // rows past the end: their (clamped) block is somebody else's
+            pdl = a.delta[bh * T + min(i, T - 1)] / dsc;
+        }
+    };
+    auto commit = [&]() {
+        stQu.store(sQu);
+        stO.store(sdO);
+        if (tid < 64) { sRs[tid] = prs; sDl[tid] = pdl; }
+    };
+    if (it_lo <= it_hi) {
+        issue(it_lo);
+        commit();
+    }
+    __syncthreads();
+    for (int it = it_lo; it <= it_hi; ++it) {
+        const int i0 = it * 64;
+        bf16x4 pu[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) pu[rb] = pun[rb];
+        if (it < it_hi) issue(it + 1);
+
+        bf16x4 pb[4], dsb[4];     // per row block: P and dS'' for rows 16rb + 4g + reg, col r16
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dp = mfma16(ld_bf16x8(sdO + 16 * rb * DH + foff[ks]), vf[ks], dp);
+            unsigned hw[2] = {0u, 0u};
+            if (DROP) dl_.words((i0 >> 4) + rb, jw_lo >> 4, hw);
+            const f32x4 rs4 = *(const f32x4*)&sRs[16 * rb + 4 * g], dl4 = *(const f32x4*)&sDl[16 * rb + 4 * g];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float p = bf2f(pu[rb][reg]) * rs4[reg];          // P' = P ln2 / (1-p)
+                float pd = p, dpe = dp[reg];
+                if (DROP) {
+                    const bool keep = drop_keep16(hw, reg, a.drop_thr, thr_hi);
+                    pd = keep ? p : 0.f;
+                    dpe = keep ? dpe : 0.f;
+                }
+                pb[rb][reg] = f2bf(pd);
+                dsb[rb][reg] = f2bf(p * (dpe - dl4[reg]));
+            }
+        }
+        // dv += P^T dO ; dk += dS''^T qu2: k-slots e<4 -> ii = 32pp+4g+e, e>=4 -> ii = 32pp+16+4g+e-4
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            bf16x8 pa, da;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pa[e] = pb[2 * pp][e]; pa[4 + e] = pb[2 * pp + 1][e];
+                da[e] = dsb[2 * pp][e]; da[4 + e] = dsb[2 * pp + 1][e];
+            }
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                dv[d] = mfma16(pa, frag_tr_rm<DH>(sdO, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * d, r16), dv[d]);
+                dk[d] = mfma16(da, frag_tr_rm<DH>(sQu, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * d, r16), dk[d]);
+            }
+        }
+        __syncthreads();
+        if (it < it_hi) commit();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int j = jw_lo + 4 * g + reg;
         if (j < K) {
             const size_t off = ((size_t)j * B + b) * a.ld_dqkv + h * DH;
 #pragma unroll
@@ -1203,6 +1421,11 @@ static bool fits_srd(const commu_attn_desc* d) {
     return K * d->B * d->ld_qkv * 2 < 0xFFFF0000ull && K * d->ld_rd * 2 < 0xFFFF0000ull;
 }
 
+/* elements of the P scratch the backward pass may be given (commu_attn_bwd_desc.p_scratch) */
+extern "C" long long commu_attn_p_scratch_elems(int T, int M, int B, int H) {
+    return (long long)B * H * ((T + 15) / 16) * ((T + M + 63) / 64) * 1024;
+}
+
 extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                                  hipStream_t stream) {
     if (d->T <= 0 || d->B <= 0) return 0;
@@ -1249,11 +1472,24 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     a.ld_dqkv = e->ld_dqkv; a.ld_dsk = e->ld_dsk;
     a.dsk_wedge = e->dsk_wedge;
     a.dsk_tiled = e->dsk_tiled;
+    a.pbuf = (bf16*)e->p_scratch;
+    if (e->p_scratch != nullptr && d->DH != 64) return -22;
     if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
     if ((e->ld_dsk % 8) || (a.dsk_tiled && ((e->ld_dsk % 128) || (((long long)d->T * d->B) % 64)))) return -22;
     if (e->du_rows != (d->T + 63) / 64) return -22;
     dim3 gq((((d->T + 63) / 64 + 1) / 2) * d->H * d->B), gk((((K + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
+    if (a.pbuf != nullptr) {          // the query-stationary kernel stores P, the key-stationary one reads it back
+        if (drop) {
+            if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, true>), gq, dim3(256), 0, stream, a);
+            if (which & 2) COMMU_LAUNCH((relattn_bwd_kv2_kernel<true>), gk, dim3(256), 0, stream, a);
+        } else {
+            if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, false>), gq, dim3(256), 0, stream, a);
+            if (which & 2) COMMU_LAUNCH((relattn_bwd_kv2_kernel<false>), gk, dim3(256), 0, stream, a);
+        }
+        COMMU_LAUNCH_CHECK();
+        return 0;
+    }
 #define ATTN_BWD(DHV)                                                                                                  \
     {                                                                                                                  \
         if (drop) {                                                                                                    \

@@ -214,7 +214,12 @@ typedef struct commu_attn_bwd_desc {
     int dsk_wedge;
     int dsk_tiled;        /* != 0: dsk is [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (the layout
                              commu_relattn_bwd_band reads; needs (T*B) % 64 == 0, ld_dsk % 128 == 0); 0: row-major */
+    void* p_scratch;      /* NULL, or (d_head 64 only) commu_attn_p_scratch_elems(T, M, B, H) bf16 elements, uninitialised:
+                             the query-stationary kernel stores the probabilities it recomputes there and the
+                             key-stationary kernel, which must then run AFTER it on the same stream, reads them
+                             back instead of recomputing (q+u).k, the band product / rel-shift, masks and exp */
 } commu_attn_bwd_desc;
+long long commu_attn_p_scratch_elems(int T, int M, int B, int H);
 int commu_attn_bwd_qrows(int T);
 int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 /* the two kernels of commu_relattn_bwd on their own: query-stationary (dq_ac, dsk, du_part) and key-stationary

@@ -102,10 +102,13 @@ def attn_keep(seed, B, H, T, K, p):
     return ops.attn_dropout_keep_mask(seed, B, H, T, K, p)
 
 
-@pytest.mark.parametrize("case", [(64, 0, 2, 2, 64), (40, 24, 2, 2, 32), (130, 0, 1, 1, 64)])
-def test_attention_dropout_fwd_bwd_exact_mask(case):
+@pytest.mark.parametrize("store_p", [False, True], ids=["recompute", "stored_p"])
+@pytest.mark.parametrize("case", [(64, 0, 2, 2, 64), (40, 24, 2, 2, 32), (130, 0, 1, 1, 64), (200, 70, 3, 2, 64)])
+def test_attention_dropout_fwd_bwd_exact_mask(case, store_p):
     from commu_amd import ops
     T, M, B, H, DH = case
+    if store_p and DH != 64:
+        pytest.skip("stored probabilities: d_head 64 kernels only")
     K, HD, p, seed = T + M, H * DH, 0.2, 424243
     g = torch.Generator().manual_seed(3)
     qkv = bf(torch.randn(K * B, 3 * HD, generator=g) * 0.7)
@@ -130,8 +133,12 @@ def test_attention_dropout_fwd_bwd_exact_mask(case):
     dqkv = torch.zeros_like(gq)
     drd = torch.zeros(K, HD, device=DEV)
     du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
-    ops.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M, out, dout.to(DEV), lse,
-                    qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=p, drop_seed=seed)
+    keep_flag, ops.STORE_ATTN_P = ops.STORE_ATTN_P, store_p
+    try:
+        ops.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M, out, dout.to(DEV), lse,
+                        qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=p, drop_seed=seed)
+    finally:
+        ops.STORE_ATTN_P = keep_flag
     gref = leaf.grad
     tol = 3e-2
     assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol

@@ -260,7 +260,7 @@ def test_out_of_range_ids_poison_the_loss():
     good = torch.ones(n, dtype=torch.bool)
     good[3] = good[17] = False
     assert torch.isnan(out[~good]).all() and torch.equal(out[good], ref[good])
-    logits = bf(rnd(n, 736, seed=12)).to(DEV)
+    logits = rnd(n, 736, seed=12).to(DEV)                  # fp32 logits, padded row pitch as in the model
     nll, _ = o.ce_fwd(logits, bad.to(DEV), V)
     nll_ref, _ = o.ce_fwd(logits, tok.to(DEV), V)
     assert torch.isnan(nll.cpu()[~good]).all() and torch.equal(nll.cpu()[good], nll_ref.cpu()[good])
@@ -475,10 +475,16 @@ def test_relattn_fwd(case):
     assert float((lse.cpu() - ref_lse).abs().max()) < 6e-3   # bf16 (q+u), (q+v) operands
 
 
+@pytest.mark.parametrize("store_p", [False, True], ids=["recompute", "stored_p"])
 @pytest.mark.parametrize("case", ATTN_CASES)
-def test_relattn_bwd(case):
+def test_relattn_bwd(case, store_p):
+    """store_p: the query-stationary kernel writes the probabilities it recomputes into a scratch buffer (poisoned with
+    NaN here) and the key-stationary kernel reads them back (d_head 64); otherwise both recompute P from (q+u).k, the
+    band product and lse.  Both against autograd of the oracle."""
     o = ops()
     T, M, B, H, DH, sl, mem_len, rc = case
+    if store_p and DH != 64:
+        pytest.skip("stored probabilities: d_head 64 kernels only")
     K = T + M
     HD = H * DH
     qkv, rd, u, vb = make_attn_inputs(T, M, B, H, DH, 40)
@@ -496,17 +502,19 @@ def test_relattn_bwd(case):
     g = qkv.to(DEV)
     rst = None if reset is None else reset.to(torch.uint8).to(DEV)
     q, k, v = g[M * B:, :HD], g[:, HD:2 * HD], g[:, 2 * HD:]
-    out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len,
-                                 save_q=True)
     dqkv = torch.zeros_like(g)
     drd = torch.zeros(K, HD, device=DEV)
     du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
+    out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len,
+                                 save_q=True)
     o.POISON_SCRATCH = True           # NaN in every scratch element the kernels are not supposed to read
+    keep_flag, o.STORE_ATTN_P = o.STORE_ATTN_P, store_p
     try:
         o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
                       dout.to(DEV), lse, qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
     finally:
         o.POISON_SCRATCH = False
+        o.STORE_ATTN_P = keep_flag
     gref = leaf.grad
     tol = 2.5e-2          # bf16 P/dS operands + bf16 outputs
     assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol, "dq"
