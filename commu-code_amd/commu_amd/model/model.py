@@ -194,14 +194,14 @@ class MemTransformerLM(nn.Module):
 
     def init_mems(self, n_layers):                                       # model.py:498-505
         if self.mem_len > 0:
-            param = next(self.parameters())
+            param = self._param_list()[0]
             return torch.empty(n_layers + 1, 0, dtype=BF16, device=param.device)
         return None
 
     def forward(self, data, target, reset_mems, mems):                   # model.py:678-693
         if mems is None:
             mems = self.init_mems(self.n_layer)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()):
             self._ensure_flat()
             loss, new_mems = _XLLoss.apply(self, data, target, reset_mems, mems, *self._flat["params"])
             if mems is None:
@@ -218,9 +218,23 @@ class MemTransformerLM(nn.Module):
             logits, new_mems, _ = self._run_forward(data, None, None, mems, need_grad=False, want_logits=True)
         return logits, new_mems
 
+    def zero_grad(self, set_to_none: bool = True):                      # nn.Module.zero_grad without the module-tree walk
+        for p in self._param_list():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_().zero_()
+
     # ------------------------------------------------------------------ flat parameter storage
     def _param_list(self):
-        return [p for _, p in self.named_parameters()]
+        # (cached: walking the module tree costs more host time per step than it looks -- the parameter OBJECTS never
+        #  change after construction; .to() / load_state_dict swap or copy their data in place)
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = [p for _, p in self.named_parameters()]
+            self.__dict__["_plist"] = pl
+        return pl
 
     def _ensure_flat(self):
         """fp32 master parameters / gradients live in two flat device buffers that the individual

@@ -68,7 +68,14 @@ def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _s():
+    # (the raw handle of torch's current stream: ~0.3 us, against ~8 us for torch.cuda.current_stream().cuda_stream --
+    #  a training step makes ~250 kernel calls)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
