@@ -313,8 +313,8 @@ def extra_rows(args, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--d-model", dest="d_model", type=int, default=512)
     ap.add_argument("--heads", type=int, default=8)

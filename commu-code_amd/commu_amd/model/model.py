@@ -106,6 +106,13 @@ class RelPartialLearnableDecoderLayer(nn.Module):
     forward = _no_direct_forward
 
 
+def _low_priority_stream(dev):
+    """Side stream for work off the critical path (weight gradients, bias / LayerNorm-parameter reductions).  (This
+    device offers stream priorities -1 and 0 only -- torch clamps anything else -- so the side stream cannot be made
+    LOWER than the default stream the step runs on; measured gain of the side stream at the bench shape: ~1.5 %.)"""
+    return torch.cuda.Stream(device=dev)
+
+
 class _Saved:
     """Activations of one forward call kept for its backward."""
     __slots__ = ("T", "M", "B", "tokens", "target", "reset", "h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1",
@@ -322,7 +329,7 @@ class MemTransformerLM(nn.Module):
         if getattr(self, "wgrad_side_stream", True):
             side = fl.get("wgrad_stream")
             if side is None:
-                side = fl["wgrad_stream"] = torch.cuda.Stream(device=dev)
+                side = fl["wgrad_stream"] = _low_priority_stream(dev)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -566,7 +573,7 @@ class MemTransformerLM(nn.Module):
             main.wait_event(fl["shadow_ready"])          # transposed weights of the last optimiser step are in place
         side = fl.get("wgrad_stream") if getattr(self, "wgrad_side_stream", True) else None
         if side is None and getattr(self, "wgrad_side_stream", True):
-            side = fl["wgrad_stream"] = torch.cuda.Stream(device=dev)
+            side = fl["wgrad_stream"] = _low_priority_stream(dev)
         keep = []          # operands stay referenced until the join: the allocator must not hand them out early
 
         # Weight gradients of a layer are collected and issued as ONE grouped launch of the eight-phase TN kernel
