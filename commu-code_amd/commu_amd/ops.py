@@ -236,6 +236,28 @@ def reduce_slabs(dst, slabs, n, nslabs, stride, accumulate, alpha=1.0):
     return dst
 
 
+def quant_mxfp8(X):
+    """bf16 [rows, K] -> (e4m3 bytes uint8 [rows, K], E8M0 scale bytes uint8 [rows, K/32])  (OCP MX, block 32)."""
+    rows, K = X.shape
+    assert X.dtype == BF16 and X.stride(1) == 1 and K % 32 == 0
+    Q = torch.empty(rows, K, device=X.device, dtype=torch.uint8)
+    S = torch.empty(rows, K // 32, device=X.device, dtype=torch.uint8)
+    call("commu_quant_mxfp8", _p(X), X.stride(0), _p(Q), K, _p(S), K // 32, rows, K, _s())
+    return Q, S
+
+
+def gemm_nt_mxfp8(A, SA, B, SB, out=None, bias=None, relu=False):
+    """out bf16 [M, N] = A . B^T with MX-fp8 operands from quant_mxfp8 (A [M, K], B [N, K]); fp32 accumulation."""
+    M, K = A.shape
+    N = B.shape[0]
+    assert A.dtype == torch.uint8 and B.dtype == torch.uint8 and B.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=BF16)
+    call("commu_gemm_nt_mxfp8", _p(A), A.stride(0), _p(SA), SA.stride(0), _p(B), B.stride(0), _p(SB), SB.stride(0), _p(out),
+         out.stride(0), M, N, K, _p(bias), 1 if relu else 0, _s())
+    return out
+
+
 def reduce_slabs_crop(dst, slabs, crop, nslabs, stride, accumulate, alpha=1.0):
     """crop = (rg, rt, rp, cg, ct, cp): the [rt, ct] blocks of the padded [rg*rp, cg*cp] product (summed over the
     slabs) are added to / stored in dst [rg*rt, cg*ct]."""
