@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             // the key-stationary kernel re-reads P instead of recomputing it (block of 16 rows x 64 keys, P^T image order)
             if (DH == 64 && pstore)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), srdP, pvoff + 512 * c,
-                                                      (((iw_lo >> 4) * JT + jt) << 11), 0);
+                                                      (((iw_lo >> 4) * JT + jt) << 11), 2 /* nt: read once, by a later kernel */);
             *(bf16x4*)(myD + pt_off(16 * c + r16, g)) = db;       // dS^T[kv][row]
             // by distance: (row 4g+reg, jj = 16c + r16) -> ring column (i + M - j0 - jj) & 127
 #pragma unroll
