@@ -264,11 +264,12 @@ def attention_roofline(args, prof, tokens_per_step, elapsed):
     shape (the GEMM entry points are a mix of shapes and tile variants; their share is in time_share).
     Algorithmic flops per launch = tokens * products * 2*Kbar*D  (Kbar = M + (T+1)/2):
       forward 3 products (QK^T, QR^T, PV); query-stationary backward 4 (QK^T, QR^T, dP, dQ);
-      key-stationary backward 5 (QK^T, QR^T, dP, dV, dK)."""
+      key-stationary backward 3 (dP, dV, dK: it re-reads the probabilities the query-stationary kernel stored; the
+      d_head-32 variant, which recomputes QK^T and QR^T, is not on the bench path)."""
     T, M = args.tgt_len, args.mem_len
     mb_tokens = tokens_per_step // args.batch_chunk
     kbar = M + (T + 1) / 2.0
-    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 5.0}
+    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 3.0}
     tot = {k: sum(v) for k, v in prof.items()}
     cnt = {k: max(1, len(v)) for k, v in prof.items()}
     dom = max(products, key=lambda k: tot.get(k, 0.0))

@@ -8,7 +8,8 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-KERNELS = {"relattn_fwd_kernel": "commu_relattn_fwd", "relattn_bwd_q_kernel": "commu_relattn_bwd_q",
+KERNELS = {"relattn_fwd2_kernel": "commu_relattn_fwd", "relattn_fwd_kernel": "commu_relattn_fwd",
+           "relattn_bwd_q_kernel": "commu_relattn_bwd_q", "relattn_bwd_kv2_kernel": "commu_relattn_bwd_kv",
            "relattn_bwd_kv_kernel": "commu_relattn_bwd_kv"}
 
 
@@ -34,7 +35,7 @@ for name in ("relattn.hip", "common.cuh"):          # the same hash bench.py com
         sha.update(f.read())
 out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": sha.hexdigest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
        "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-extra`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB",
-       "fetch_kib_raw": {KERNELS[k]: fetch.get(k) for k in KERNELS}, "write_kib_raw": {KERNELS[k]: write.get(k) for k in KERNELS},
-       "bytes_per_launch": {KERNELS[k]: (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in KERNELS}}
+       "fetch_kib_raw": {KERNELS[k]: fetch[k] for k in fetch}, "write_kib_raw": {KERNELS[k]: write[k] for k in write},
+       "bytes_per_launch": {KERNELS[k]: (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in fetch}}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
