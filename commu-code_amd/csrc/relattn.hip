@@ -855,6 +855,14 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     __syncthreads();
     const int iw_lo = i0 + 16 * w, iw_hi = iw_lo + 15;
     const size_t mrow0 = (size_t)T * B;
+    // dS-by-distance flush: descriptor of this head's [T*B][ld_dsk] (tiled or row-major) block, per-lane row offset in bytes
+    const srd_t srdD = make_srd(a.dsk + (size_t)h * mrow0 * a.ld_dsk, mrow0 * a.ld_dsk * 2);
+    const int fl_i = iw_lo + (lane >> 2);
+    unsigned fl_row;
+    {
+        const unsigned m = (unsigned)min(fl_i, T - 1) * (unsigned)B + (unsigned)b;
+        fl_row = a.dsk_tiled ? (((m >> 6) * (unsigned)(a.ld_dsk >> 7)) << 14) + ((m & 63u) << 8) : m * (unsigned)a.ld_dsk * 2u;
+    }
     for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
         const int j0 = jt * 64;
         if (jt < jt_hi) issue(jt + 1);
@@ -927,22 +935,18 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         __builtin_amdgcn_wave_barrier();
         // flush: row r (distance dl = i + M - j0 at jj = 0) completed the aligned chunks 8c in [dl - 63, dl]
         if (a.dsk_wedge != -7) {
+            // lane (row = lane >> 2, k = lane & 3): chunks c = c0 + k and c0 + k + 4 of its row; the row's part of the address
+            // (fl_row) is per query tile, the descriptor is per head, a false predicate becomes an out-of-range offset
+            const int dl0 = fl_i + M - j0;
+            const int c0 = ((dl0 - 56) >> 3) + (lane & 3);          // ceil((dl - 63) / 8) + k
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int row = lane >> 2, i = iw_lo + row;
-                const int dl = i + M - j0;
-                const int c = ((dl - 56) >> 3) + (lane & 3) + 4 * n;          // ceil((dl - 63) / 8) + k
-                if (i < T && c >= 0 && 8 * c <= dl) {
-                    const bf16x8 v8 = *(const bf16x8*)(myS + row * SPITCH + ((8 * c) & (SRING - 1)));
-                    const size_t m = (size_t)i * B + b;
-                    bf16* dst;
-                    if (a.dsk_tiled)
-                        dst = a.dsk + ((((size_t)h * (mrow0 >> 6) + (m >> 6)) * (a.ld_dsk >> 7) + (c >> 4)) << 13) +
-                              ((m & 63) << 7) + ((8 * c) & 127);
-                    else
-                        dst = a.dsk + ((size_t)h * mrow0 + m) * a.ld_dsk + 8 * c;
-                    *(bf16x8*)dst = v8;
-                }
+                const int c = c0 + 4 * n;
+                const bf16x8 v8 = *(const bf16x8*)(myS + (lane >> 2) * SPITCH + ((8 * c) & (SRING - 1)));
+                unsigned off = a.dsk_tiled ? fl_row + (((unsigned)(c >> 4) << 13) + (unsigned)((8 * c) & 127)) * 2u
+                                           : fl_row + (unsigned)(8 * c) * 2u;
+                if (!(fl_i < T && c >= 0 && 8 * c <= dl0)) off = 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), srdD, (int)off, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1477,6 +1481,7 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
     if ((e->ld_dsk % 8) || (a.dsk_tiled && ((e->ld_dsk % 128) || (((long long)d->T * d->B) % 64)))) return -22;
     if (e->du_rows != (d->T + 63) / 64) return -22;
+    if ((size_t)d->T * d->B * e->ld_dsk * 2 >= 0x7FFF0000ull) return -22;          // the flush addresses one head's block with 32-bit offsets
     dim3 gq((((d->T + 63) / 64 + 1) / 2) * d->H * d->B), gk((((K + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
     if (a.pbuf != nullptr) {          // the query-stationary kernel stores P, the key-stationary one reads it back
