@@ -133,7 +133,14 @@ _prof = None
 
 def profile_start(names):
     global _prof
-    _prof = {"names": set(names), "events": {n: [] for n in names}}
+    _prof = {"names": set(names), "events": {n: [] for n in names}, "on": True}
+
+
+def profile_enable(on: bool):
+    """Pause / resume event recording inside a profile_start .. profile_stop window (the events cost a few per cent of a
+    training step when every call is bracketed; sampling some of the steps keeps the timed region honest)."""
+    if _prof is not None:
+        _prof["on"] = bool(on)
 
 
 def profile_stop():
@@ -149,7 +156,7 @@ def profile_stop():
 def call(name, *args):
     """Call an entry point and raise on a non-zero status."""
     fn = getattr(load(), name)
-    if _prof is not None and name in _prof["names"]:
+    if _prof is not None and _prof["on"] and name in _prof["names"]:
         import torch
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
