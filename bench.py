@@ -222,6 +222,8 @@ def train_bench(args, dev, world, rank, steps, warmup):
     model.train()
     if args.no_side_stream:
         model.wgrad_side_stream = False
+    if getattr(args, "fp8_forward", False):
+        model.fp8_forward = True          # the layers' forward Linear products in MX-fp8 (BASELINE.json configs[4])
     reducer = GradReducer() if world > 1 else None
     if reducer is not None:
         reducer.broadcast_params(model)
@@ -295,6 +297,8 @@ EXTRA_ROWS = [
      dict(d_model=500, heads=10, d_inner=1000, tgt_len=128, mem_len=1024, batch_per_gpu=256, batch_chunk=4)),
     ("cfg5_L12_D1024_H16_DI2048_T2048_M2048_b8_bf16",
      dict(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048, batch_per_gpu=8)),
+    ("cfg5_L12_D1024_H16_DI2048_T2048_M2048_b8_mxfp8_forward_gemms",
+     dict(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048, batch_per_gpu=8, fp8_forward=True)),
 ]
 
 
@@ -304,7 +308,7 @@ def extra_rows(args, dev):
         a = argparse.Namespace(**{**vars(args), **over})
         # warm-up until the XL memory has reached its full length (tgt_len 128 / mem_len 1024: nine segments), so that
         # the timed steps run at the steady-state shapes
-        steps, warmup = 8, max(5, a.mem_len // a.tgt_len + 3)
+        steps, warmup = 8, max(8, a.mem_len // a.tgt_len + 6)          # (the caching allocator settles ~5 steps after the memory is full)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         elapsed, tps, prof, pscale = train_bench(a, dev, 1, 0, steps, warmup)
@@ -333,6 +337,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU shape rows")
+    ap.add_argument("--fp8-forward", dest="fp8_forward", action="store_true",
+                    help="forward Linear products of the layers in MX-fp8 (opt-in; bf16 is the default and the headline)")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="weight-gradient work on the main stream (default: a side stream)")
     args = ap.parse_args()

@@ -50,7 +50,7 @@ PROTOTYPES = {
     "commu_reduce_slabs2d_f32": [c_p, c_i, C.c_longlong, c_p, c_i, c_i, c_i, c_z, c_i, c_i, c_f, c_p],
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
     "commu_quant_mxfp8": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p],
-    "commu_gemm_nt_mxfp8": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "commu_gemm_nt_mxfp8": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, C.c_uint, c_f, c_p],
     "commu_reduce_slabs_crop_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_z, c_i, c_f, c_p],
     "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
     "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, C.c_uint, c_f, c_p],

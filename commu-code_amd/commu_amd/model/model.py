@@ -404,6 +404,19 @@ class MemTransformerLM(nn.Module):
                 "w2": bv(pre + "pos_ff.CoreNet.3.weight", (D, DI)),
                 "b1": lay.pos_ff.CoreNet[0].bias, "b2": lay.pos_ff.CoreNet[3].bias}
 
+    def _weights_fp8(self, i):
+        """MX-fp8 (bytes, scales) of layer i's four Linear weights, re-quantised whenever the parameters changed
+        (`fp8_forward`, BASELINE.json configs[4])."""
+        fl = self._flat
+        cache = fl.setdefault("fp8", {})
+        if cache.get("version") != fl["version"]:
+            cache.clear()
+            cache["version"] = fl["version"]
+        if i not in cache:
+            w = self._weights(i)
+            cache[i] = {k: ops.quant_mxfp8(w[k]) for k in ("qkv", "o", "w1", "w2")}
+        return cache[i]
+
     def _emb_bf16(self):
         """[V, Dp] bf16 embedding / output-layer weight."""
         if self._padded:
@@ -475,25 +488,39 @@ class MemTransformerLM(nn.Module):
         u, vb = self._uv()
         h_out = None
         kv_out = []
+        fp8 = bool(getattr(self, "fp8_forward", False))
+        if fp8 and (self._padded or D % 128 or DI % 128 or HD % 128):
+            raise CommuHipError("fp8_forward needs d_model, d_inner and n_head * d_head to be multiples of 128")
         for i in range(L):
             w = self._weights(i)
             s0 = 16 + 4 * i
             qkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
             cat = None
+            # fp8_forward (opt-in, BASELINE.json configs[4]): the four Linear products of the layer's FORWARD in OCP MX-fp8
+            # (activations quantised on the fly, weights once per optimiser step); backward stays bf16 on the saved bf16
+            # activations.  Needs K % 128 == 0 for every contraction.
+            f8 = self._weights_fp8(i) if fp8 else None
             if M > 0:                                                            # K4 over [mem; h] (model.py:283-288)
                 cat = mems[i].reshape(M * B, D)
                 if cat.dtype != BF16:
                     cat = cat.to(BF16)
-                ops.gemm_nt(cat, w["qkv"][HD:], out=qkv[:M * B, HD:])
-            ops.gemm_nt(h, w["qkv"], out=qkv[M * B:])
+                if fp8:
+                    ops.linear_mxfp8(cat, (f8["qkv"][0][HD:], f8["qkv"][1][HD:]), out=qkv[:M * B, HD:])
+                else:
+                    ops.gemm_nt(cat, w["qkv"][HD:], out=qkv[:M * B, HD:])
+            if fp8:
+                ops.linear_mxfp8(h, f8["qkv"], out=qkv[M * B:])
+            else:
+                ops.gemm_nt(h, w["qkv"], out=qkv[M * B:])
             rd = ops.gemm_nt(pd, w["r"])                                         # K5
             vec, lse, qs = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
                                            T, M, B, H, DH, bool(self.same_length), int(self.mem_len),
                                            save_q=need_grad, drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale)    # K6
-            z1 = ops.gemm_nt(vec, w["o"], resid=h, drop_p=p, drop_seed=ss(s0 + 1))             # K7
+            lin = (lambda x, k, **e: ops.linear_mxfp8(x, f8[k], **e)) if fp8 else (lambda x, k, **e: ops.gemm_nt(x, w[k], **e))
+            z1 = lin(vec, "o", resid=h, drop_p=p, drop_seed=ss(s0 + 1))                         # K7
             a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)
-            hid = ops.gemm_nt(a, w["w1"], bias=w["b1"], relu=True, drop_p=p, drop_seed=ss(s0 + 2))   # K8
-            z2 = ops.gemm_nt(hid, w["w2"], bias=w["b2"], resid=a, drop_p=p, drop_seed=ss(s0 + 3))
+            hid = lin(a, "w1", bias=w["b1"], relu=True, drop_p=p, drop_seed=ss(s0 + 2))         # K8
+            z2 = lin(hid, "w2", bias=w["b2"], resid=a, drop_p=p, drop_seed=ss(s0 + 3))
             if i == L - 1 and p > 0:          # final `self.drop(core_out)` (model.py:601) as a second LN output
                 h_out = torch.empty(TB, D, device=dev, dtype=BF16)
             y, mu2, rs2 = ops.layernorm_fwd(z2, lay[i].pos_ff.layer_norm.weight, lay[i].pos_ff.layer_norm.bias,

@@ -246,16 +246,26 @@ def quant_mxfp8(X):
     return Q, S
 
 
-def gemm_nt_mxfp8(A, SA, B, SB, out=None, bias=None, relu=False):
-    """out bf16 [M, N] = A . B^T with MX-fp8 operands from quant_mxfp8 (A [M, K], B [N, K]); fp32 accumulation."""
+def gemm_nt_mxfp8(A, SA, B, SB, out=None, bias=None, relu=False, resid=None, drop_p=0.0, drop_seed=0):
+    """out bf16 [M, N] = A . B^T with MX-fp8 operands from quant_mxfp8 (A [M, K], B [N, K]); fp32 accumulation; the
+    epilogue (bias -> ReLU -> dropout -> residual) is commu_gemm_nt_bf16's."""
     M, K = A.shape
     N = B.shape[0]
     assert A.dtype == torch.uint8 and B.dtype == torch.uint8 and B.shape[1] == K
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=BF16)
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (EPI_RESID if resid is not None else 0) | \
+            (EPI_DROPOUT if drop_p > 0 else 0)
     call("commu_gemm_nt_mxfp8", _p(A), A.stride(0), _p(SA), SA.stride(0), _p(B), B.stride(0), _p(SB), SB.stride(0), _p(out),
-         out.stride(0), M, N, K, _p(bias), 1 if relu else 0, _s())
+         out.stride(0), M, N, K, _p(bias), _p(resid), 0 if resid is None else resid.stride(0), flags, int(drop_seed),
+         float(drop_p), _s())
     return out
+
+
+def linear_mxfp8(x, wq, out=None, **epi):
+    """x bf16 [M, K] quantised on the fly, wq = (bytes, scales) of the weight: one Linear in MX-fp8."""
+    xq, xs = quant_mxfp8(x)
+    return gemm_nt_mxfp8(xq, xs, wq[0], wq[1], out=out, **epi)
 
 
 def reduce_slabs_crop(dst, slabs, crop, nslabs, stride, accumulate, alpha=1.0):

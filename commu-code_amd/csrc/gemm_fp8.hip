@@ -74,7 +74,10 @@ struct F8Args {
     const unsigned char *A, *SA, *B, *SB;
     bf16* C;
     const float* bias;
-    int lda, ldsa, ldb, ldsb, ldc, M, N, K, relu;
+    const bf16* resid;
+    int lda, ldsa, ldb, ldsb, ldc, ldr, M, N, K, flags;
+    unsigned drop_seed, drop_thr;
+    float drop_scale;
 };
 
 constexpr int TM = 128, TN = 128, TK = 128;          // TK in bytes = k elements
@@ -178,11 +181,17 @@ __global__ __launch_bounds__(256) void gemm_nt_mxfp8_kernel(const F8Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + 64 * wn + 16 * j + r16;
-            const float bv = (a.bias != nullptr && col < a.N) ? a.bias[col] : 0.f;
+            const float bv = ((a.flags & COMMU_EPI_BIAS) && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
+                // same order and the same dropout element index (m * N + n) as commu_gemm_nt_bf16: the backward pass
+                // regenerates the masks from (seed, index)
+                const int row = m0 + 64 * wm + 16 * i + 4 * g + reg;
                 float x = acc[i][j][reg] + bv;
-                if (a.relu) x = fmaxf(x, 0.f);
+                if (a.flags & COMMU_EPI_RELU) x = fmaxf(x, 0.f);
+                if (a.flags & COMMU_EPI_DROPOUT)
+                    x = drop_keep(a.drop_seed, (unsigned)row * (unsigned)a.N + (unsigned)col, a.drop_thr) ? x * a.drop_scale : 0.f;
+                if ((a.flags & COMMU_EPI_RESID) && row < a.M && col < a.N) x += bf2f(a.resid[(size_t)row * a.ldr + col]);
                 ep[(16 * i + 4 * g + reg) * 72 + 16 * j + r16] = f2bf(x);
             }
         }
@@ -211,15 +220,19 @@ extern "C" int commu_quant_mxfp8(const void* X, int ldx, void* Q, int ldq, void*
 }
 
 extern "C" int commu_gemm_nt_mxfp8(const void* A, int lda, const void* SA, int ldsa, const void* B, int ldb, const void* SB,
-                                   int ldsb, void* C, int ldc, int M, int N, int K, const float* bias, int relu,
-                                   hipStream_t stream) {
+                                   int ldsb, void* C, int ldc, int M, int N, int K, const float* bias, const void* resid,
+                                   int ldr, int flags, unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K % 128) || (lda % 16) || (ldb % 16) || (ldsa % 4) || (ldsb % 4) || (ldc % 8) || lda < K || ldb < K ||
         ldsa < K / 32 || ldsb < K / 32)
         return -22;
     if ((size_t)M * lda >= 0x7FFF0000ull || (size_t)N * ldb >= 0x7FFF0000ull) return -22;
+    if (flags & ~(COMMU_EPI_BIAS | COMMU_EPI_RELU | COMMU_EPI_RESID | COMMU_EPI_DROPOUT)) return -22;
+    if (((flags & COMMU_EPI_BIAS) && !bias) || ((flags & COMMU_EPI_RESID) && !resid)) return -22;
     F8Args a = {(const unsigned char*)A, (const unsigned char*)SA, (const unsigned char*)B, (const unsigned char*)SB, (bf16*)C,
-                bias, lda, ldsa, ldb, ldsb, ldc, M, N, K, relu};
+                bias, (const bf16*)resid, lda, ldsa, ldb, ldsb, ldc, ldr, M, N, K, flags, drop_seed,
+                (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0), 1.f / (1.f - drop_p)};
+    if (!(flags & COMMU_EPI_DROPOUT) || drop_p <= 0.f) a.flags &= ~COMMU_EPI_DROPOUT;
     const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
     COMMU_LAUNCH(gemm_nt_mxfp8_kernel, dim3(tiles), dim3(256), 0, stream, a);
     COMMU_LAUNCH_CHECK();

@@ -90,12 +90,14 @@ int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch_stride, co
  * product of commu_gemm_nt_bf16 with both operands in OCP e4m3 and one E8M0 scale per 32 k, OCP microscaling v1.0).
  * commu_quant_mxfp8: X bf16 [rows][ldx] -> Q e4m3 bytes [rows][ldq] + S scale bytes [rows][lds]; K % 32 == 0.
  *   block scale 2^(floor(log2 amax) - 8), elements rounded to nearest even, saturating at +-448.
- * commu_gemm_nt_mxfp8: C bf16 [M][ldc] = A . B^T (+ bias[N]) (ReLU if relu != 0), fp32 accumulation on
+ * commu_gemm_nt_mxfp8: C bf16 [M][ldc] = A . B^T with the epilogue flags BIAS, RELU, DROPOUT, RESID of
+ *   commu_gemm_nt_bf16 (same order, same dropout element index), fp32 accumulation on
  *   v_mfma_scale_f32_16x16x128_f8f6f4; K % 128 == 0, lda/ldb % 16 == 0, ldsa/ldsb % 4 == 0, ldc % 8 == 0, else -22.
  * Tolerance against the bf16 path is set by e4m3's 3 mantissa bits (tests/test_fp8_gemm_gpu.py states it). */
 int commu_quant_mxfp8(const void* X, int ldx, void* Q, int ldq, void* S, int lds, int rows, int K, hipStream_t stream);
 int commu_gemm_nt_mxfp8(const void* A, int lda, const void* SA, int ldsa, const void* B, int ldb, const void* SB, int ldsb,
-                        void* C, int ldc, int M, int N, int K, const float* bias, int relu, hipStream_t stream);
+                        void* C, int ldc, int M, int N, int K, const float* bias, const void* resid, int ldr, int flags,
+                        unsigned drop_seed, float drop_p, hipStream_t stream);
 
 /* cropping form for zero-padded models (d_head 50 -> 64 ...): the slabs hold the padded [rg*rp, cg*cp] product, its
  * [rt, ct] blocks go to dst [rg*rt, cg*ct]:

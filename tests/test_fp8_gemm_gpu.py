@@ -76,3 +76,69 @@ def test_gemm_nt_mxfp8_rejects_bad_shapes():
     sa = torch.zeros(16, 4, dtype=torch.uint8, device=DEV)
     with pytest.raises(CommuHipError):
         ops.gemm_nt_mxfp8(qa, sa, qa, sa)          # K % 128 != 0
+
+
+def test_gemm_nt_mxfp8_epilogue_matches_bf16_kernel_conventions():
+    """bias -> ReLU -> dropout -> residual, with the dropout mask of commu_gemm_nt_bf16 (element index m * N + n): the
+    backward pass regenerates that mask, so the two kernels must agree on it exactly."""
+    from commu_amd import ops
+    M, N, K, p, seed = 130, 256, 256, 0.3, 4242
+    a = (rnd(M, K, seed=6) * 0.8).to(torch.bfloat16)
+    b = (rnd(N, K, seed=7) * 0.05).to(torch.bfloat16)
+    bias, resid = rnd(N, seed=8), rnd(M, N, seed=9).to(torch.bfloat16)
+    _, _, da = mx_quant_ref(a)
+    _, _, db = mx_quant_ref(b)
+    keep = ops.dropout_keep_mask(seed, M * N, p).view(M, N)
+    thr = min(int(p * 4294967296.0), 4294967295)
+    ref = (da.double() @ db.double().t() + bias.double()).clamp_min(0) * keep / (1 - p) + resid.double()
+    qa, sa = ops.quant_mxfp8(a.to(DEV))
+    qb, sb = ops.quant_mxfp8(b.to(DEV))
+    out = ops.gemm_nt_mxfp8(qa, sa, qb, sb, bias=bias.to(DEV), relu=True, resid=resid.to(DEV), drop_p=p, drop_seed=seed)
+    assert relerr(out, ref) < 8e-3
+    # the same call through the bf16 kernel drops exactly the same elements
+    out_bf = ops.gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV), relu=True, resid=resid.to(DEV), drop_p=p, drop_seed=seed)
+    dropped8 = (out.float().cpu() - resid.float()).abs() < 1e-6
+    dropped16 = (out_bf.float().cpu() - resid.float()).abs() < 1e-6
+    pos = (ref - resid.double()).abs() > 0.25          # kept elements that are clearly non-zero
+    assert bool(dropped8[~keep].all()) and bool(dropped16[~keep].all())
+    assert not bool(dropped8[pos & keep].any()) and not bool(dropped16[pos & keep].any())
+
+
+def test_model_fp8_forward_option():
+    """`fp8_forward`: the four Linear products of every layer's forward in MX-fp8 (BASELINE.json configs[4]).  Against
+    the bf16 path of the same model on the same batch: per-token loss within 0.15 (values ~6.6), every gradient tensor
+    with cosine >= 0.97, and the loss goes down over optimiser steps."""
+    import math
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import Trainer, build_model
+    dev = torch.device(DEV)
+    cfg = get_cfg(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=128, mem_length=128, batch_size=8,
+                  batch_chunk=1, dropout=0.0, attention_dropout=0.0)
+    d, t, r, n = synthetic_batch(128, 8, dev, seed=5)
+    losses, grads = {}, {}
+    for mode in (False, True):
+        model = build_model(cfg, BaseVocab(), dev, seed=3)
+        model.eval()
+        model.fp8_forward = mode
+        mems = None
+        for seg in range(2):                                         # second segment runs with XL memory (cat path)
+            loss, mems = model(d, t, torch.zeros_like(r), mems)
+        model.zero_grad()
+        loss.float().mean().backward()
+        losses[mode] = loss.detach().float().cpu()
+        grads[mode] = {k: p.grad.detach().float().cpu().flatten() for k, p in model.named_parameters() if p.grad is not None}
+    err = (losses[True] - losses[False]).abs()
+    assert float(err.max()) < 0.15 and float(err.mean()) < 0.03, (float(err.max()), float(err.mean()))
+    for k in grads[False]:
+        a, b = grads[True][k], grads[False][k]
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.97, (k, cos)
+    cfg2 = get_cfg(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=128, mem_length=0, batch_size=8,
+                   batch_chunk=1, dropout=0.1, attention_dropout=0.1)
+    model = build_model(cfg2, BaseVocab(), dev, seed=3)
+    model.train()
+    model.fp8_forward = True
+    tr = Trainer(model, cfg2, num_gpus=1)
+    ls = [float(tr.step(d, t, r, n)) for _ in range(8)]
+    assert all(math.isfinite(x) for x in ls) and ls[-1] < ls[1] - 0.05, ls
