@@ -492,7 +492,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
     call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
     # fused band pass (commu_relattn_bwd_band: dq_BD and dRd in ONE sweep over dS-by-distance) when the shape allows
-    band_slabs = call("commu_attn_band_slabs", T, B) if (DH == 64 and K <= 1024 and not NO_FUSED_BAND) else 0
+    band_slabs = call("commu_attn_band_slabs", T, B) if (DH == 64 and K <= 4096 and not NO_FUSED_BAND) else 0
     ld_dsk = round_up(K, 128) if band_slabs else round_up(K, 32)
     # dS by distance is lower-triangular (d <= i + M).  Without same_length / reset masks the two GEMMs below only
     # visit the band (half the work) and the kernel only writes the triangle.  What lies right of the causal edge
@@ -552,14 +552,15 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     TB = T * B
     if band_slabs:
         # one pass: dq = dq_ac + dsk . Rd on this stream; the dRd partial slabs are reduced off the critical path
-        slabs = torch.empty(H * band_slabs * 1024 * DH, device=dev, dtype=F32)
+        kpad = round_up(K, 512)          # slab rows: the kernel works in passes of 512 distances
+        slabs = torch.empty(H * band_slabs * kpad * DH, device=dev, dtype=F32)
         call("commu_relattn_bwd_band", _p(dsk), ld_dsk, _p(rd), rd.stride(0), _p(qv2), qv2.stride(0), _p(dq_ac), HD,
              _p(dq), dq.stride(0), _p(slabs), T, M, B, H, DH, 1 if band else 0, _s())
 
         def drd_reduce():
             if defer is not None:
                 slabs.record_stream(torch.cuda.current_stream())
-            call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, band_slabs, 1024 * DH, H, 0,
+            call("commu_reduce_slabs2d_f32", _p(drd), drd.stride(0), DH, _p(slabs), K, DH, band_slabs, kpad * DH, H, 0,
                  1.0 / c2, _s())
         if defer is None:
             drd_reduce()

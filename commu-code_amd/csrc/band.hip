@@ -31,7 +31,7 @@ constexpr int SBYTES = 64 * CH * 2;      // dSk chunk image [64 m][128 d] (16 KB
 constexpr int RHALF = 512;               // distances of Rd[:, h] resident per pass
 constexpr int RBYTES = RHALF * 64 * 2;   // Rd half image [512 d][64 f] (64 KB)
 constexpr int QBYTES = 64 * 64 * 2;      // qv step image [64 m][64 f] (8 KB)
-constexpr int KMAX = 1024;               // distances a workgroup accumulates (8 chunks, 2 passes)
+constexpr int KMAX = 4096;               // largest K: passes of RHALF = 512 distances (4 chunks each), any number of them
 constexpr int NRING = 3;                 // dSk chunk buffers: one being read, two in flight
 constexpr int NSTEPBUF = 3;              // per-step tiles (qv, residual dq rows): steps with a chunk in the ring
 
@@ -103,11 +103,9 @@ __global__ __launch_bounds__(512) void band_bwd_kernel(const BandArgs a) {
         for (int j = 0; j < 4; ++j) sNT[j] = rowb + ((((j * 4) ^ (X & 12)) | (g ^ (X & 3))) << 4);          // dSk rows (NT, B operand)
     }
 
-    f32x4 accR[8][4];          // dRd[chunk][feature block] of distance block w: D[f = 4g + reg][d = r16]
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) accR[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accR[4][4];          // dRd[chunk of the pass][feature block] of distance block w: D[f = 4g + reg][d = r16]
+    const int kpad = ((a.K + RHALF - 1) / RHALF) * RHALF;          // slab rows
+    float* slab = a.slabs + ((size_t)h * a.P + pair) * (size_t)kpad * 64;
 
     // Two passes over the workgroup's token rows: pass p keeps distances 512 p .. 512 p + 511 of Rd[:, h] RESIDENT in LDS
     // (64 KB) and streams only dSk, 16 KB per chunk through a ring of three buffers (two chunks in flight).  With a
@@ -122,6 +120,8 @@ __global__ __launch_bounds__(512) void band_bwd_kernel(const BandArgs a) {
     }
 #define BAND_PASS(PASS)                                                                                              \
     {                                                                                                                \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) accR[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};                  \
         auto slice_of = [&](int sub) { return sub == 0 ? pair : 2 * a.P - 1 - pair; };                               \
         auto nchunks = [&](int st) {          /* chunks of THIS pass that step st reaches (0 .. 4) */                \
             int keff = a.K;                                                                                          \
@@ -202,10 +202,10 @@ __global__ __launch_bounds__(512) void band_bwd_kernel(const BandArgs a) {
             }                                                                                                        \
             /* dRd += dSk^T . qv for this chunk (static accumulator index: one copy of the body per chunk) */        \
             if (!(a.abl & 4)) switch (q0.c) {                                                                        \
-                case 0: BAND_TN(4 * (PASS)) break;                                                                   \
-                case 1: BAND_TN(4 * (PASS) + 1) break;                                                               \
-                case 2: BAND_TN(4 * (PASS) + 2) break;                                                               \
-                default: BAND_TN(4 * (PASS) + 3) break;                                                              \
+                case 0: BAND_TN(0) break;                                                                            \
+                case 1: BAND_TN(1) break;                                                                            \
+                case 2: BAND_TN(2) break;                                                                            \
+                default: BAND_TN(3) break;                                                                           \
             }                                                                                                        \
             /* dq += dSk . Rd over this chunk's 128 distances */                                                     \
             if (!(a.abl & 4)) _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                     \
@@ -243,20 +243,19 @@ __global__ __launch_bounds__(512) void band_bwd_kernel(const BandArgs a) {
             slot = slot == 2 ? 0 : slot + 1;                                                                                   \
             __syncthreads();                                                                                         \
         }                                                                                                            \
+        /* dRd slab rows of this pass: [512][64] fp32, lane holds slab[d = .. + r16][f = .. + 4g + reg] */           \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                              \
+            const int d = RHALF * (PASS) + c * CH + w * 16 + r16;                                                    \
+            _Pragma("unroll") for (int fb = 0; fb < 4; ++fb)                                                         \
+                *(f32x4*)(slab + (size_t)d * 64 + fb * 16 + 4 * g) = accR[c][fb];                                    \
+        }                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* (the next pass counts its own loads from zero) */ \
+        __syncthreads();                                                                                             \
     }
-    BAND_PASS(0)
-    if (a.K > RHALF) BAND_PASS(1)
+    const int npass = kpad / RHALF;
+    for (int pass = 0; pass < npass; ++pass) BAND_PASS(pass)
 #undef BAND_TN
 #undef BAND_PASS
-
-    // ---- dRd slab of this workgroup: [KMAX][64] fp32, lane holds slab[d = .. + r16][f = .. + 4g + reg]
-    float* slab = a.slabs + ((size_t)h * a.P + pair) * (size_t)(KMAX * 64);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int d = c * CH + w * 16 + r16;
-#pragma unroll
-        for (int fb = 0; fb < 4; ++fb) *(f32x4*)(slab + (size_t)d * 64 + fb * 16 + 4 * g) = accR[c][fb];
-    }
 }
 
 }  // namespace

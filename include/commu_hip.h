@@ -240,10 +240,11 @@ int commu_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hi
 int commu_relattn_bwd_q(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 int commu_relattn_bwd_kv(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 /* The two per-head GEMMs above fused into ONE pass over dsk (band.hip): dq = dq_ac + dsk . Rd (bf16, written in
- * place with row stride ld_dq) and slabs[(h * P + p)][1024][64] = partial dsk^T . qv2 of token-slice pair p, with
- * P = commu_attn_band_slabs(T, B); the caller finishes with
- *   commu_reduce_slabs2d_f32(dRd, ld, 64, slabs, K, 64, P, 1024 * 64, H, 0, 1 / (scale * log2 e)).
- * dsk must be TILED (commu_attn_bwd_desc.dsk_tiled).  Needs DH == 64, T + M <= 1024, ld_dsk % 128 == 0, (T * B) % 64 == 0
+ * place with row stride ld_dq) and slabs[(h * P + p)][Kp][64] = partial dsk^T . qv2 of token-slice pair p, with
+ * P = commu_attn_band_slabs(T, B) and Kp = T + M rounded up to 512 (the kernel runs one pass per 512 distances,
+ * keeping that part of Rd resident in LDS); the caller finishes with
+ *   commu_reduce_slabs2d_f32(dRd, ld, 64, slabs, K, 64, P, Kp * 64, H, 0, 1 / (scale * log2 e)).
+ * dsk must be TILED (commu_attn_bwd_desc.dsk_tiled).  Needs DH == 64, T + M <= 4096, ld_dsk % 128 == 0, (T * B) % 64 == 0
  * and >= 8192 (else -22: use the two GEMMs on a row-major dsk).
  * band != 0: rows are causal (see commu_gemm_nt_bf16_batched, tri_B = B, tri_M = M) and only the chunks of 256
  * distances that reach the causal edge are read; what lies beyond the edge inside them must be zero. */

@@ -5,10 +5,10 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-decode --no-extra "$@" > $out/bench.json 2> $out/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 bench.py --steps ${PROF_STEPS:-6} --warmup ${PROF_WARMUP:-2} --no-cpu-baseline --no-decode --no-extra "$@" > $out/bench.json 2> $out/err.log
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-decode --no-extra $@"
+  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps ${PROF_STEPS:-6} --warmup ${PROF_WARMUP:-2} --no-cpu-baseline --no-decode --no-extra $@"
   python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -443,6 +443,10 @@ ATTN_CASES = [
     (128, 0, 64, 2, 64, False, 0, None),
     (160, 130, 52, 1, 64, False, 130, None),
     (96, 32, 96, 2, 64, True, 100, 3),
+    # more than 1024 key positions: the fused band pass runs one pass per 512 distances (the reference's released
+    # default shape tgt_len 128 / mem_len 1024, and a masked variant)
+    (128, 1024, 64, 1, 64, False, 1024, None),
+    (128, 1100, 64, 1, 64, True, 1100, 2),
 ]
 
 
