@@ -724,9 +724,9 @@ class MemTransformerLM(nn.Module):
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]
+            # (the q third of the memory rows is never written and never read: memory rows have no query, their weight
+            #  gradient and dX only take the k|v thirds -- no zero fill)
             dqkv = torch.empty(K * B, 3 * HD, device=dev, dtype=BF16)
-            if M > 0:
-                dqkv[:M * B, :HD].zero_()
             drd = torch.empty(K, HD, device=dev, dtype=F32)
             if scr_free[i & 1] is not None:
                 main.wait_event(scr_free[i & 1])          # (layer i+2's dRd GEMM has released this scratch buffer)
