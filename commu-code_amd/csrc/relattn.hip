@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
 // measured too: the 128-register forward kernel pays more for the extra stores than both backward kernels gain.)
 // key-stationary: dk, dv (as relattn_bwd_kv_kernel: wave w owns key columns 16w..16w+15 of the 64-column tile).
 template <bool DROP>
-__global__ __launch_bounds__(256) void relattn_bwd_kv2_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void relattn_bwd_kv2_kernel(const AttnArgs a) {
     constexpr int DH = 64, NW = 4, KS = 2, DB = 4, KCOLS = 64, NTHR = 256;
     __shared__ __attribute__((aligned(16))) bf16 sQu[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sdO[64 * DH];
@@ -1325,10 +1325,23 @@ __global__ __launch_bounds__(256) void relattn_bwd_kv2_kernel(const AttnArgs a) 
                 pa[e] = pb[2 * pp][e]; pa[4 + e] = pb[2 * pp + 1][e];
                 da[e] = dsb[2 * pp][e]; da[4 + e] = dsb[2 * pp + 1][e];
             }
+            // the four operand fragments of a feature-block pair (8 transpose reads) are requested before their MFMAs: left
+            // alone hipcc emits read, read, wait, MFMA sixteen times and every MFMA pays a full LDS latency
 #pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                dv[d] = mfma16(pa, frag_tr_rm<DH>(sdO, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * d, r16), dv[d]);
-                dk[d] = mfma16(da, frag_tr_rm<DH>(sQu, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * d, r16), dk[d]);
+            for (int dp2 = 0; dp2 < DB; dp2 += 2) {
+                bf16x8 fo[2], fq[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    fo[d] = frag_tr_rm<DH>(sdO, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * (dp2 + d), r16);
+                    fq[d] = frag_tr_rm<DH>(sQu, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, 16 * (dp2 + d), r16);
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    dv[dp2 + d] = mfma16(pa, fo[d], dv[dp2 + d]);
+                    dk[dp2 + d] = mfma16(da, fq[d], dk[dp2 + d]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
         __syncthreads();
