@@ -698,8 +698,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             *(bf16x4*)(myP + pt_off(16 * c + r16, g)) = pb;       // P^T[kv][row]: rows 4g..4g+3
         }
         __builtin_amdgcn_wave_barrier();
-        // (requesting the operand fragments ahead of their MFMAs -- source-level batching plus sched_group_barrier --
-        //  was measured: the extra live registers cost more than the exposed LDS latency at four waves per SIMD)
+        // (requesting ALL operand fragments of a phase ahead of its MFMAs -- source-level batching plus
+        //  sched_group_barrier -- was measured: the extra live registers cost more than the exposed LDS latency at four
+        //  waves per SIMD; two feature blocks at a time fits the register budget and is worth ~2 %)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 pf;
@@ -708,11 +709,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 pf[0] = lo[0]; pf[1] = lo[1]; pf[2] = lo[2]; pf[3] = lo[3]; pf[4] = hi[0]; pf[5] = hi[1]; pf[6] = hi[2]; pf[7] = hi[3];
             }
 #pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                const bf16x4 lo = tr8(((vb + vo[0]) ^ (32 * d)) + 4096 * ks), hi = tr8(((vb + vo[1]) ^ (32 * d)) + 4096 * ks);
-                bf16x8 vf;
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3]; vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                o[d] = mfma16(pf, vf, o[d]);
+            for (int d2 = 0; d2 < DB; d2 += 2) {          // two feature blocks' V fragments (4 transpose reads) ahead of their MFMAs
+                bf16x8 vf[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const bf16x4 lo = tr8(((vb + vo[0]) ^ (32 * (d2 + d))) + 4096 * ks), hi = tr8(((vb + vo[1]) ^ (32 * (d2 + d))) + 4096 * ks);
+                    vf[d][0] = lo[0]; vf[d][1] = lo[1]; vf[d][2] = lo[2]; vf[d][3] = lo[3];
+                    vf[d][4] = hi[0]; vf[d][5] = hi[1]; vf[d][6] = hi[2]; vf[d][7] = hi[3];
+                }
+#pragma unroll
+                for (int d = 0; d < 2; ++d) o[d2 + d] = mfma16(pf, vf[d], o[d2 + d]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();                         // P image is rewritten by the next tile
