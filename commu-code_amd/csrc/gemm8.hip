@@ -616,6 +616,9 @@ bool gemm8_nt_eligible(int M, int N, int K, int lda, int ldb, int batch, int tri
     if (batch != 1 || tri_B != 0) return false;
     if ((flags & COMMU_EPI_RESID) && (flags & COMMU_EPI_RELUMASK)) return false;          // one auxiliary operand per call
     if (M < 1024 || N < 256 || K < 128 || (K % 64) != 0) return false;
+    // fewer output tiles than CUs: the persistent kernel's fixed cost (~20 us) is not amortised and three quarters of the
+    // chip idle -- the 128 x 128 / 256 x 128 tiled kernels take these (8192 x 512 x 512: 14 us against 22 us)
+    if (((M + 255) / 256) * ((N + 255) / 256) < 256 && !getenv("COMMU_GEMM8_ALWAYS")) return false;
     if ((size_t)M * lda * 2 >= 0xFFFF0000ull || (size_t)N * ldb * 2 >= 0xFFFF0000ull) return false;      // 32-bit buffer offsets
     if ((size_t)256 * lda * 2 >= 0x7FFF0000ull || (size_t)256 * ldb * 2 >= 0x7FFF0000ull) return false;
     return true;

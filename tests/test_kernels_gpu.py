@@ -114,6 +114,7 @@ def test_gemm_nt_layernorm_fused_decode_form(M, N, K, D):
                                    (4096, 1024, 1024)])
 def test_gemm_nt_eight_phase(M, N, K, grid, monkeypatch):
     o = ops()
+    monkeypatch.setenv("COMMU_GEMM8_ALWAYS", "1")          # (the dispatcher only takes it from 256 output tiles on)
     if grid:
         monkeypatch.setenv("COMMU_GEMM8_GRID", str(grid))
     A, B = bf(rnd(M, K, seed=21)), bf(rnd(N, K, seed=22))
@@ -145,9 +146,10 @@ def test_gemm_nt_eight_phase(M, N, K, grid, monkeypatch):
     assert relerr(out, ref * keep / (1 - p) + resid.float()) < F32_TOL
 
 
-def test_gemm_nt_eight_phase_asymmetric_identity():
+def test_gemm_nt_eight_phase_asymmetric_identity(monkeypatch):
     """A = [I; 0...] pattern with an asymmetric B: catches transposed / permuted C writes of the 8-phase kernel."""
     o = ops()
+    monkeypatch.setenv("COMMU_GEMM8_ALWAYS", "1")
     M, N, K = 1024, 512, 128
     A = torch.zeros(M, K)
     for m in range(M):
