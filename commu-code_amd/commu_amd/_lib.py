@@ -31,6 +31,11 @@ class AttnBwdDesc(C.Structure):
                 ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i), ("p_scratch", c_p)]
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [("dst", c_p), ("src_off", C.c_longlong), ("rg", c_i), ("rt", c_i), ("rp", c_i), ("cg", c_i), ("ct", c_i),
+                ("cp", c_i)]
+
+
 class TnProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("lda", c_i), ("ldb", c_i), ("N", c_i), ("K", c_i), ("out_off", C.c_longlong)]
 
@@ -51,6 +56,7 @@ PROTOTYPES = {
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
     "commu_quant_mxfp8": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_gemm_nt_mxfp8": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, C.c_uint, c_f, c_p],
+    "commu_reduce_slabs_group_f32": [C.POINTER(ReduceItem), c_i, c_p, c_i, c_z, c_i, c_f, c_p],
     "commu_reduce_slabs_crop_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_z, c_i, c_f, c_p],
     "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
     "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, C.c_uint, c_f, c_p],

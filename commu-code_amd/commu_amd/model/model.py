@@ -793,15 +793,16 @@ class MemTransformerLM(nn.Module):
             fl["slabs"] = torch.empty(need, device=fl["dev"], dtype=F32)
         slabs = fl["slabs"]
         ops.gemm_tn_grouped(arr, Mtok, slabs, total, ns)
+        red = []
         for (dY, Xa, gW, rows, crop), off in zip(items, offs):
             N, Kc = dY.shape[1], Xa.shape[1]
             if crop is not None:
                 rg, rt, rp, cg, ct, cp = crop
                 assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)
-                ops.reduce_slabs_crop(gW, slabs[off:], crop, ns, total, True)
             else:
-                nrows = N if rows is None else rows
-                ops.reduce_slabs(gW, slabs[off:], nrows * Kc, ns, total, True, 1.0)
+                crop = (1, N if rows is None else rows, N, 1, Kc, Kc)
+            red.append((gW, off, crop))
+        ops.reduce_slabs_group(red, slabs, ns, total, True)          # one launch for the whole group
 
     def _tn_acc(self, dY, Xa, gW, rows=None, crop=None):
         """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads.

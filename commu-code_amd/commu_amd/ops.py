@@ -268,6 +268,18 @@ def linear_mxfp8(x, wq, out=None, **epi):
     return gemm_nt_mxfp8(xq, xs, wq[0], wq[1], out=out, **epi)
 
 
+def reduce_slabs_group(items, slabs, nslabs, stride, accumulate, alpha=1.0):
+    """items = [(dst fp32 contiguous, src_off, crop (rg, rt, rp, cg, ct, cp))]: every reduction of a grouped
+    weight-gradient launch in ONE launch (<= 8 items)."""
+    arr = (_lib.ReduceItem * len(items))()
+    for i, (dst, off, crop) in enumerate(items):
+        rg, rt, rp, cg, ct, cp = crop
+        assert dst.is_contiguous() and dst.dtype == F32 and dst.numel() >= rg * rt * cg * ct
+        arr[i].dst, arr[i].src_off = dst.data_ptr(), off
+        arr[i].rg, arr[i].rt, arr[i].rp, arr[i].cg, arr[i].ct, arr[i].cp = rg, rt, rp, cg, ct, cp
+    call("commu_reduce_slabs_group_f32", arr, len(items), _p(slabs), nslabs, stride, 1 if accumulate else 0, float(alpha), _s())
+
+
 def reduce_slabs_crop(dst, slabs, crop, nslabs, stride, accumulate, alpha=1.0):
     """crop = (rg, rt, rp, cg, ct, cp): the [rt, ct] blocks of the padded [rg*rp, cg*cp] product (summed over the
     slabs) are added to / stored in dst [rg*rt, cg*ct]."""

@@ -847,6 +847,55 @@ extern "C" int commu_reduce_slabs_crop_f32(float* dst, const float* src, int rg,
     return 0;
 }
 
+// All slab reductions of a grouped weight-gradient launch in ONE launch: item z (blockIdx.y) is the cropping form above
+// applied to its own block of the slabs and its own destination (a plain reduction is the crop (1, rows, rows_padded, 1,
+// cols, cols)).
+struct ReduceGroup {
+    commu_reduce_item it[8];
+};
+__global__ void reduce_slabs_group_kernel(ReduceGroup grp, const float* __restrict__ slabs, int nslabs, size_t stride,
+                                          int accumulate, float alpha) {
+    const commu_reduce_item& it = grp.it[blockIdx.y];
+    const float* src = slabs + it.src_off;
+    float* dst = it.dst;
+    const int rt = it.rt, rp = it.rp, cg = it.cg, ct = it.ct, cp = it.cp;
+    const size_t n = (size_t)it.rg * rt * cg * ct;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ct);
+        size_t q = i / ct;
+        const int c = (int)(q % cg);
+        q /= cg;
+        const int r = (int)(q % rt), g = (int)(q / rt);
+        const size_t j = (((size_t)g * rp + r) * cg + c) * cp + k;
+        float v = src[j];
+        for (int z = 1; z < nslabs; ++z) v += src[(size_t)z * stride + j];
+        v *= alpha;
+        if (accumulate) v += dst[i];
+        dst[i] = v;
+    }
+}
+
+extern "C" int commu_reduce_slabs_group_f32(const commu_reduce_item* items, int nitems, const float* slabs, int nslabs,
+                                            size_t stride, int accumulate, float alpha, hipStream_t stream) {
+    if (nitems <= 0) return 0;
+    if (nitems > 8 || nslabs <= 0) return -22;
+    ReduceGroup grp;
+    size_t nmax = 0;
+    for (int i = 0; i < nitems; ++i) {
+        grp.it[i] = items[i];
+        if (items[i].rt > items[i].rp || items[i].ct > items[i].cp || items[i].rg <= 0 || items[i].cg <= 0) return -22;
+        const size_t n = (size_t)items[i].rg * items[i].rt * items[i].cg * items[i].ct;
+        nmax = n > nmax ? n : nmax;
+    }
+    size_t blocks = (nmax + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) return 0;
+    COMMU_LAUNCH(reduce_slabs_group_kernel, dim3((unsigned)blocks, nitems), dim3(256), 0, stream, grp, slabs, nslabs, stride,
+                 accumulate, alpha);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- grouped weight-gradient GEMM (gemm8.hip: gemm_tn8_kernel)
 static bool tn_group_plan(const commu_tn_problem* probs, int nprob, int M, Tn8Args* out) {
     if (nprob <= 0 || nprob > 8) return false;

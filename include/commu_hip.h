@@ -104,6 +104,16 @@ int commu_gemm_nt_mxfp8(const void* A, int lda, const void* SA, int ldsa, const 
  *   dst[((a*rt + r)*cg + c)*ct + k] (+)= alpha * sum_s src[s*stride + ((a*rp + r)*cg + c)*cp + k] */
 int commu_reduce_slabs_crop_f32(float* dst, const float* src, int rg, int rt, int rp, int cg, int ct, int cp,
                                 int nslabs, size_t stride, int accumulate, float alpha, hipStream_t stream);
+/* all reductions of a grouped weight-gradient launch in one: item z applies the cropping form to slabs + src_off with
+ * its own destination (plain reduction of [rows, cols] out of a padded [rows_p, cols] block: (1, rows, rows_p, 1, cols,
+ * cols)); nitems <= 8 */
+typedef struct commu_reduce_item {
+    float* dst;
+    long long src_off;          /* element offset of the item's block inside a slab */
+    int rg, rt, rp, cg, ct, cp;
+} commu_reduce_item;
+int commu_reduce_slabs_group_f32(const commu_reduce_item* items, int nitems, const float* slabs, int nslabs, size_t stride,
+                                 int accumulate, float alpha, hipStream_t stream);
 /* dst[i] = (accumulate ? dst[i] : 0) + alpha * sum_s src[s*stride + i] */
 int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, size_t stride,
                            int accumulate, float alpha, hipStream_t stream);

@@ -300,6 +300,31 @@ def test_reduce_slabs_crop():
     assert float((dst - full).abs().max()) < 1e-5
 
 
+def test_reduce_slabs_group():
+    """Every slab reduction of a grouped weight-gradient launch in one launch: plain, row-limited and cropped items."""
+    o = ops()
+    ns, total = 3, 64 * 96 + 768 * 32 + 6 * 64 * 2 * 128
+    stride = total + 24
+    slabs = rnd(ns, stride, seed=60).to(DEV)
+    summed = slabs.sum(0)
+    items, want = [], []
+    d0 = rnd(64, 96, seed=61).to(DEV)                                   # plain [64, 96]
+    items.append((d0, 0, (1, 64, 64, 1, 96, 96)))
+    want.append(d0 + summed[:64 * 96].view(64, 96))
+    off = 64 * 96
+    d1 = rnd(729, 32, seed=62).to(DEV)                                  # first 729 of 768 rows
+    items.append((d1, off, (1, 729, 768, 1, 32, 32)))
+    want.append(d1 + summed[off:off + 768 * 32].view(768, 32)[:729])
+    off += 768 * 32
+    d2 = rnd(6 * 50, 2 * 100, seed=63).to(DEV)                          # cropped [6 x 50 of 64, 2 x 100 of 128]
+    items.append((d2, off, (6, 50, 64, 2, 100, 128)))
+    want.append(d2 + summed[off:off + 6 * 64 * 2 * 128].view(6, 64, 2, 128)[:, :50, :, :100].reshape(300, 200))
+    want = [w.clone() for w in want]
+    o.reduce_slabs_group(items, slabs, ns, stride, True)
+    for (dst, _, _), w in zip(items, want):
+        assert float((dst - w).abs().max()) < 1e-5
+
+
 def test_posemb_distance_order():
     o = ops()
     K, D = 37, 64
