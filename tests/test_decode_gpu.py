@@ -40,6 +40,37 @@ def test_sampling_probs_match_reference(golden_dir):
             assert int(tok) == Dz.draw_inverse_cdf(torch.from_numpy(ref), 0.5)
 
 
+def test_sampling_topk_selection_matches_torch_topk():
+    """The kept set is torch.topk's (radix-select threshold + ties in id order), with and without a rejection mask; a zero
+    mask changes nothing; rejected tokens lose their mass and the rest is renormalised."""
+    from commu_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for trial in range(3):
+        logits = torch.randn(64, 729, generator=g) * (1 + 2 * trial)
+        p = torch.softmax(torch.cat([torch.full((64, 1), float("-inf")), logits[:, 1:] / 0.95], 1), 1)
+        top = p.topk(32, dim=1).indices
+        ref_keep = torch.zeros(64, 729, dtype=torch.bool).scatter_(1, top, True)
+        outs = []
+        for mode in ("none", "zeros", "reject"):
+            wrong = None
+            if mode != "none":
+                wrong = torch.zeros(64, 729, dtype=torch.uint8)
+                if mode == "reject":
+                    wrong[torch.arange(64), top[:, 0]] = 1          # reject every row's most likely token
+                    wrong[:, 5] = 1
+            pr = torch.zeros(64, 729, device=DEV)
+            ops.sample_topk(logits.clone().to(DEV), 0.95, 32, wrong=None if wrong is None else wrong.to(DEV),
+                            uniforms=torch.full((64,), 0.5, device=DEV), probs_out=pr)
+            outs.append(pr.cpu())
+            want = p * ref_keep
+            if mode == "reject":
+                want = want * (wrong == 0)
+            want = want / want.sum(1, keepdim=True)
+            assert torch.equal(pr.cpu() > 0, want > 0), (trial, mode)
+            assert float((pr.cpu() - want).abs().max()) < 2e-6, (trial, mode)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_sampling_draw_is_inverse_cdf():
     from commu_amd import ops
     g = torch.Generator().manual_seed(5)
