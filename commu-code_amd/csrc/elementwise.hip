@@ -182,8 +182,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 
 // dz = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  partial column sums of
 // dy*xhat (dgamma), dy (dbeta) and dz (bias grad of the Linear feeding the LN) per block.
-constexpr int LNB_ROWS = 64;   // rows per block (16 per wave)
+constexpr int LNB_ROWS = 32;   // rows per block (8 per wave: 8192 waves at 65536 rows, two per SIMD slot pair)
+constexpr int LNB_WROWS = LNB_ROWS / 4;
 
+// Bandwidth kernel (2 reads + 2 writes of a [rows, D] bf16 tensor): a wave walks its rows TWO at a time -- two independent
+// reduction chains -- with the next pair's operands and row statistics already in flight (4 rows x 2 x 16 bytes per lane).
 template <int NC>          // NC 8-element chunks per lane: D <= 512 * NC
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ z, int ldz,
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     bf16* __restrict__ dz, int lddz, float* __restrict__ part, int rows, int D, bf16* __restrict__ dzm,
     int lddzm, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     __shared__ float red[4][3][512 * NC];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float ag[NC][8], ab[NC][8], az[NC][8], gm[NC][8];
     bool act[NC], hi[NC], padc[NC];          // chunk has valid columns / its upper 4 are valid / pure padding to zero
     const int Dz = min(lddz, (D + 63) & ~63);
@@ -207,65 +210,87 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
             gm[c][e] = (col < D) ? gamma[col] : 0.f;
         }
     }
-    const int r0 = blockIdx.x * LNB_ROWS + w * 16;
-    const int nr = min(16, rows - r0);
+    const int r0 = blockIdx.x * LNB_ROWS + w * LNB_WROWS;
+    const int nr = min(LNB_WROWS, rows - r0);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    bf16x8 vz[NC], vd[NC], nz[NC], nd[NC];
-    auto fetch = [&](int row, bf16x8* pz, bf16x8* pd) {
+    const unsigned key = mix32(drop_seed);
+    const float invD = 1.f / (float)D;
+    bf16x8 vz[2][NC], vd[2][NC], nz[2][NC], nd[2][NC];
+    float vmu[2], vrs[2], nmu[2], nrs[2];
+    auto fetch = [&](int row) {          // rows row, row+1 (clamped: a pair past the end re-reads the last row, unused)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int col = lane * 8 + 512 * c;
-            pz[c] = act[c] ? ld_bf16x8(z + (size_t)row * ldz + col) : zero8;
-            pd[c] = act[c] ? ld_bf16x8(dy + (size_t)row * lddy + col) : zero8;
-        }
-    };
-    if (nr > 0) fetch(r0, nz, nd);
-    for (int rr = 0; rr < nr; ++rr) {
-        const int row = r0 + rr;
+        for (int u = 0; u < 2; ++u) {
+            const int r = min(row + u, rows - 1);
+            nmu[u] = mean[r];
+            nrs[u] = rstd[r];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { vz[c] = nz[c]; vd[c] = nd[c]; }
-        if (rr + 1 < nr) fetch(row + 1, nz, nd);          // next row's loads fly under this row's reductions
-        const float mu = mean[row], rs = rstd[row];
-        float xh[NC][8], gy[NC][8];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool ok = act[c] && (e < 4 || hi[c]);
-                const float d = ok ? bf2f(vd[c][e]) : 0.f;
-                xh[c][e] = ok ? (bf2f(vz[c][e]) - mu) * rs : 0.f;
-                gy[c][e] = d * gm[c][e];
-                s1 += gy[c][e];
-                s2 += gy[c][e] * xh[c][e];
-                ag[c][e] += d * xh[c][e];
-                ab[c][e] += d;
+            for (int c = 0; c < NC; ++c) {
+                const int col = lane * 8 + 512 * c;
+                nz[u][c] = act[c] ? ld_bf16x8(z + (size_t)r * ldz + col) : zero8;
+                nd[u][c] = act[c] ? ld_bf16x8(dy + (size_t)r * lddy + col) : zero8;
             }
         }
-        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    };
+    if (nr > 0) fetch(r0);
+    for (int rr = 0; rr < nr; rr += 2) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int col = lane * 8 + 512 * c;
-            if (act[c]) {
-                bf16x8 o, om;
+        for (int u = 0; u < 2; ++u) {
+            vmu[u] = nmu[u];
+            vrs[u] = nrs[u];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { vz[u][c] = nz[u][c]; vd[u][c] = nd[u][c]; }
+        }
+        if (rr + 2 < nr) fetch(r0 + rr + 2);          // the next pair's loads fly under this pair's reductions
+        float xh[2][NC][8], gy[2][NC][8], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool live = rr + u < nr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float v = (e < 4 || hi[c]) ? rs * (gy[c][e] - m1 - xh[c][e] * m2) : 0.f;
-                    o[e] = f2bf(v);
-                    if (dzm != nullptr) {
-                        // gradient w.r.t. the pre-dropout Linear output that fed this LayerNorm
-                        const float vm = drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr) ? v * drop_scale : 0.f;
-                        om[e] = f2bf(vm);
-                        az[c][e] += bf2f(om[e]);
-                    } else {
-                        az[c][e] += bf2f(o[e]);
-                    }
+                    const bool ok = live && act[c] && (e < 4 || hi[c]);
+                    const float d = ok ? bf2f(vd[u][c][e]) : 0.f;
+                    xh[u][c][e] = ok ? (bf2f(vz[u][c][e]) - vmu[u]) * vrs[u] : 0.f;
+                    gy[u][c][e] = d * gm[c][e];
+                    s1[u] += gy[u][c][e];
+                    s2[u] += gy[u][c][e] * xh[u][c][e];
+                    ag[c][e] += d * xh[u][c][e];
+                    ab[c][e] += d;
                 }
-                st_bf16x8(dz + (size_t)row * lddz + col, o);
-                if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, om);
-            } else if (padc[c]) {
-                st_bf16x8(dz + (size_t)row * lddz + col, zero8);
-                if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, zero8);
+            }
+        }
+        float m1[2], m2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { m1[u] = wave_sum(s1[u]) * invD; m2[u] = wave_sum(s2[u]) * invD; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = r0 + rr + u;
+            if (rr + u >= nr) break;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = lane * 8 + 512 * c;
+                if (act[c]) {
+                    bf16x8 o, om;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (e < 4 || hi[c]) ? vrs[u] * (gy[u][c][e] - m1[u] - xh[u][c][e] * m2[u]) : 0.f;
+                        o[e] = f2bf(v);
+                        if (dzm != nullptr) {
+                            // gradient w.r.t. the pre-dropout Linear output that fed this LayerNorm
+                            const bool keep = mix32k((unsigned)row * (unsigned)D + (unsigned)(col + e), key) >= drop_thr;
+                            om[e] = f2bf(keep ? v * drop_scale : 0.f);
+                            az[c][e] += bf2f(om[e]);
+                        } else {
+                            az[c][e] += bf2f(o[e]);
+                        }
+                    }
+                    st_bf16x8(dz + (size_t)row * lddz + col, o);
+                    if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, om);
+                } else if (padc[c]) {
+                    st_bf16x8(dz + (size_t)row * lddz + col, zero8);
+                    if (dzm != nullptr) st_bf16x8(dzm + (size_t)row * lddzm + col, zero8);
+                }
             }
         }
     }
