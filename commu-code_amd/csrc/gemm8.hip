@@ -170,8 +170,59 @@ __device__ __forceinline__ void g8_store(const G8Args& a, f32x4 (&acc)[4][8], in
     }
 }
 
+// Pipelined epilogue: ONE quadrant of an interior wave's outputs -- column half J (32 columns), row half XH (64 rows) --
+// through bias -> relu -> dropout, stored as four 16-byte pieces per lane; the quadrant's accumulators are cleared for the
+// output tile that is already being accumulated.  Called from the main loop, one quadrant per phase of the NEXT tile's
+// first K-tile (phase p's MFMAs are the first to touch quadrant p again), so the conversion, the hash and the store
+// issue of one wave row run under the other row's MFMAs instead of in a burst with the matrix pipe idle.
+__device__ __forceinline__ bool g8_interior(const G8Args& a, int mbase, int nbase) {
+    return (mbase + 128 <= a.M) && (nbase + 64 <= a.N) && (a.ldc % 8) == 0;
+}
+
+template <bool OUT_F32, int J, int XH>
+__device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc)[4][8], const float (&bv)[8], int mbase,
+                                         int nbase, int r16, int g) {
+    const int N = a.N;
+    const int n = nbase + 32 * J + 8 * g;
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+        const int mi = 4 * XH + m4;
+        const int m = mbase + 16 * mi + r16;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[2 * J + (e >> 2)][mi][e & 3];
+        if (flags & COMMU_EPI_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        }
+        if (flags & COMMU_EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (flags & COMMU_EPI_DROPOUT) {
+            const unsigned key = mix32(a.drop_seed), i0 = (unsigned)m * (unsigned)N + (unsigned)n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = mix32k(i0 + (unsigned)e, key) >= a.drop_thr ? v[e] * a.drop_scale : 0.f;
+        }
+        if (OUT_F32) {
+            float* C = (float*)a.C + (size_t)m * a.ldc + n;
+            *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+            st_bf16x8((bf16*)a.C + (size_t)m * a.ldc + n, o);
+        }
+        acc[2 * J][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[2 * J + 1][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // ABL (profiling only, COMMU_GEMM8_ABL): 1 = no MFMA, 2 = no staging after the prologue, 3 = no output stores
-template <bool OUT_F32, int ABL = 0>
+// PIPE: the finished tile of an interior wave is written during the next tile's first K-tile (g8_drain; epilogues without an
+// auxiliary operand) instead of in one burst
+template <bool OUT_F32, int ABL = 0, bool PIPE = false>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES + 8 * 4096];          // + edge-tile scratch
     const int tid = threadIdx.x, lane = tid & 63;
@@ -254,6 +305,32 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
 
     Cur c0{0, 0, 0, 0}, c1, c2;
     settile(c0);
+    // pipelined epilogue (PIPE): the finished tile of an interior wave is drained during the next tile's first K-tile
+    bool pend = false;
+    int pmb = 0, pnb = 0, bnb = -1;
+    const int pflags = a.flags;
+    float bvl[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bvl[j][e] = 0.f;
+    auto load_bias = [&](int nb) {          // this wave's 2 x 8 bias values per lane (reloaded only when the tile column changes)
+        if (!(a.flags & COMMU_EPI_BIAS) || nb == bnb || nb + 64 > a.N) return;
+        bnb = nb;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 b0 = *(const f32x4*)(a.bias + nb + 32 * j + 8 * g), b1 = *(const f32x4*)(a.bias + nb + 32 * j + 8 * g + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bvl[j][e] = b0[e]; bvl[j][4 + e] = b1[e]; }
+        }
+        // consumed HERE as far as the compiler can tell: its s_waitcnt for these loads lands in this (rare) branch and not,
+        // as vmcnt(0), in front of every drain of the main loop -- where it would empty the staging queue
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bvl[j][e]));
+    };
+    if (PIPE) load_bias(c0.n0 + wc * 64);
     c1 = c0;
     advance(c1);
     c2 = c1;
@@ -299,6 +376,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             xf[mi][1] = G8_FRAG(pbo + Q_XLO * HT_BYTES + xo1 + mi * 2048);
         }
         if (v1) stage(Q_WLO, c1, pb ^ 1);
+        if (PIPE && pend) g8_drain<OUT_F32, 0, 0>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -317,6 +395,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             wf[ni][1] = G8_FRAG(pbo + Q_WHI * HT_BYTES + wo1 + ni * 2048);
         }
         if (v2) stage(Q_XLO, c2, pb);
+        if (PIPE && pend) g8_drain<OUT_F32, 1, 0>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -335,6 +414,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             xf[mi][1] = G8_FRAG(pbo + Q_XHI * HT_BYTES + xo1 + mi * 2048);
         }
         if (v2) stage(Q_WHI, c2, pb);
+        if (PIPE && pend) g8_drain<OUT_F32, 1, 1>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -353,8 +433,16 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             wf[ni][0] = G8_FRAG(pbo + Q_WLO * HT_BYTES + wo0 + ni * 2048);
             wf[ni][1] = G8_FRAG(pbo + Q_WLO * HT_BYTES + wo1 + ni * 2048);
         }
-        if (v2) {
-            stage(Q_XHI, c2, pb);
+        if (v2) stage(Q_XHI, c2, pb);
+        if (PIPE && pend) {
+            g8_drain<OUT_F32, 0, 1>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
+            // (vmcnt retires in order: the K-tile needed next was complete with phase 1's Wlo pieces; younger than those are the
+            //  three half-tiles of phases 2-4 and the 4 x 4 (fp32 output: 4 x 8) output stores of the four drains)
+            if (!v2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (OUT_F32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            pend = false;
+        } else if (v2) {
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // all but the three half-tiles staged in phases 2-4
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -372,17 +460,30 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
         G8_BAR();
         // ---------------- end of an output tile: write it out (the next tile's loads are already in flight)
         if (c0.kt == nk - 1 && (ABL != 3 || acc[0][0][0] == 1234.5f)) {
-            g8_store<OUT_F32>(a, acc, c0.m0 + wr * 128, c0.n0 + wc * 64, r16, g,
-                             (LDS_AS float*)(smem + 2 * BUF_BYTES + w * 4096), lane);
+            const int mb = c0.m0 + wr * 128, nb = c0.n0 + wc * 64;
+            if (PIPE && g8_interior(a, mb, nb) && !(a.flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK))) {
+                pend = true;
+                pmb = mb;
+                pnb = nb;
+                if (PIPE) load_bias(nb);
+            } else {
+                g8_store<OUT_F32>(a, acc, mb, nb, r16, g, (LDS_AS float*)(smem + 2 * BUF_BYTES + w * 4096), lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
         c0 = c1;
         c1 = c2;
         advance(c2);
         pb ^= 1;
+    }
+    if (PIPE && pend) {          // the last tile of this workgroup
+        g8_drain<OUT_F32, 0, 0>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
+        g8_drain<OUT_F32, 1, 0>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
+        g8_drain<OUT_F32, 1, 1>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
+        g8_drain<OUT_F32, 0, 1>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
     }
     if (wr == 0) G8_BAR();          // pairs with the stagger barrier of the second wave row
 #undef G8_FRAG
@@ -640,8 +741,11 @@ int launch_gemm8_nt(const G8Args& a_in, hipStream_t stream) {
     a.store_mode = 0;
     if (const char* e = getenv("COMMU_GEMM8_ST")) a.store_mode = atoi(e);
 #define G8_LAUNCH(F32, AB) COMMU_LAUNCH((gemm_nt8_kernel<F32, AB>), dim3(grid), dim3(512), 0, stream, a)
+    const bool pipe = getenv("COMMU_GEMM8_NOPIPE") == nullptr;
     if (a.flags & COMMU_EPI_OUT_F32) {
         G8_LAUNCH(true, 0);
+    } else if (pipe && abl == 0 && !(a.flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK))) {
+        COMMU_LAUNCH((gemm_nt8_kernel<false, 0, true>), dim3(grid), dim3(512), 0, stream, a);
     } else {
         switch (abl) {
             case 1: G8_LAUNCH(false, 1); break;

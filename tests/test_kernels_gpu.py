@@ -146,6 +146,35 @@ def test_gemm_nt_eight_phase(M, N, K, grid, monkeypatch):
     assert relerr(out, ref * keep / (1 - p) + resid.float()) < F32_TOL
 
 
+@pytest.mark.parametrize("grid", [0, 2, 5])
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 128), (2300, 729, 192), (1041, 1536, 512)])
+def test_gemm_nt_eight_phase_pipelined_epilogue(M, N, K, grid, monkeypatch):
+    """bf16 output without an auxiliary operand: interior waves write a finished tile during the next tile's first K-tile
+    (gemm8.hip g8_drain).  Bit-identical to the burst epilogue (COMMU_GEMM8_NOPIPE) for plain, bias+relu and
+    bias+relu+dropout, with several tiles per workgroup (grid 2, 5), edge tiles in the mix, K-tiles 2, 3, 8."""
+    o = ops()
+    monkeypatch.setenv("COMMU_GEMM8_ALWAYS", "1")
+    if grid:
+        monkeypatch.setenv("COMMU_GEMM8_GRID", str(grid))
+    A, B, bias = bf(rnd(M, K, seed=31)).to(DEV), bf(rnd(N, K, seed=32)).to(DEV), rnd(N, seed=33).to(DEV)
+    ld = (N + 7) // 8 * 8
+    ref = A.float() @ B.float().t()
+
+    def run(**kw):
+        out = torch.full((M, ld), float("nan"), device=DEV, dtype=torch.bfloat16)[:, :N]
+        return o.gemm_nt(A, B, out=out, **kw)
+    cases = [dict(), dict(bias=bias, relu=True), dict(bias=bias, relu=True, drop_p=0.1, drop_seed=77)]
+    pipe = [run(**kw) for kw in cases]
+    monkeypatch.setenv("COMMU_GEMM8_NOPIPE", "1")
+    burst = [run(**kw) for kw in cases]
+    for a_, b_ in zip(pipe, burst):
+        assert torch.equal(a_, b_)
+    assert relerr(pipe[0], ref) < BF16_TOL
+    assert relerr(pipe[1], torch.relu(ref + bias)) < BF16_TOL
+    keep = o.dropout_keep_mask(77, M * N, 0.1).view(M, N).to(ref.device)
+    assert relerr(pipe[2], torch.relu(ref + bias) * keep / 0.9) < BF16_TOL
+
+
 def test_gemm_nt_eight_phase_asymmetric_identity(monkeypatch):
     """A = [I; 0...] pattern with an asymmetric B: catches transposed / permuted C writes of the 8-phase kernel."""
     o = ops()
