@@ -765,13 +765,14 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sD[NW * 64 * PT];
     __shared__ float red[NW][DH];
-    // dS-by-distance leaves through a per-wave ring [16 rows][128 distances] (distance mod 128, row pitch 136 elements:
-    // the four row groups of a write land 16 banks apart).  Element (row, jj) of a key tile IS distance
-    // d = i + M - j0 - jj: it is written straight to column d & 127 of its row -- the skew is absorbed by the LDS
-    // address (no permutes, no selects, no range checks; masked positions carry dS = 0) -- and leaves for HBM as whole
-    // aligned 16-byte chunks, 8 per row and key tile (the chunks the tile completed).
-    constexpr int SRING = 128, SPITCH = 136;
-    __shared__ __attribute__((aligned(16))) bf16 sS[NW * 16 * SPITCH];
+    // dS-by-distance leaves through a per-wave ring [16 rows][128 distances] (row r holds distance d at column
+    // (d + 32 (r >> 2)) mod 128: the four row groups of a write land 16 banks apart, rows are 256 bytes so the column bits
+    // and the row bits of the byte address do not overlap).  Element (row, jj) of a key tile IS distance
+    // d = i + M - j0 - jj: it is written straight to its column -- the skew is absorbed by the LDS address: one add and one
+    // and-or per element, no permutes, no selects, no range checks; masked positions carry dS = 0 -- and leaves for HBM
+    // as whole aligned 16-byte chunks, 8 per row and key tile (the chunks the tile completed).
+    constexpr int SRING = 128, SPITCH = 128;
+    __shared__ __attribute__((aligned(256))) bf16 sS[NW * 16 * SPITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
     const int QT = (a.T + QROWS - 1) / QROWS;
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     int qslot, h, b;
     tile_coords(QH, a.H, a.B, qslot, h, b);
     bf16* myS = sS + w * 16 * SPITCH;
+    const unsigned sbase = (unsigned)(size_t)(LDS_AS bf16*)sS + (unsigned)(w * 16 * SPITCH * 2 + 1024 * (int)((threadIdx.x & 63) >> 4));
     for (int rep = 0; rep < 2; ++rep) {
     const int qt = rep == 0 ? QT - 1 - qslot : qslot;
     if (rep == 1 && qt >= QT - 1 - qslot) break;
@@ -805,14 +807,15 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             dof[ks] = ld_bf16x8(dop + 32 * ks + 8 * g);
         }
     }
-    float lse2[4], dl[4];
+    // -lse2 and -delta/dsc are the INITIAL values of the score / dP accumulators (the MFMA's C operand): no subtraction per element
+    f32x4 nls, ndl;
     int srcaddr[4];
     bool lower[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int i = min(i0 + 16 * w + 4 * g + reg, T - 1);
-        lse2[reg] = a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E - __log2f(a.scale * dsc);
-        dl[reg] = a.delta[((size_t)b * a.H + h) * T + i] / dsc;
+        nls[reg] = __log2f(a.scale * dsc) - a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E;
+        ndl[reg] = -a.delta[((size_t)b * a.H + h) * T + i] / dsc;
         srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
         lower[reg] = r16 < 4 * g + reg;
     }
@@ -878,7 +881,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            s[c] = dp[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s[c] = nls;
+            dp[c] = ndl;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s[c] = mfma16(qu[ks], ld_bf16x8(sK + 16 * c * DH + foff[ks]), s[c]);
@@ -915,7 +919,9 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             }
         }
         // dS = P (dP - delta) scale
-        const int dcol0 = iw_lo + 4 * g + M - j0 - r16;          // distance of (row 4g, jj = r16)
+        // byte column of (row 4g, jj = r16) in the rotated ring, before the wrap: 2 (distance + 32 g); sbase: the LDS byte
+        // address of row 4g (a multiple of 256: the column byte is OR-ed in)
+        const int dcolb = 2 * (iw_lo + 4 * g + M - j0 - r16 + 32 * g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 db;
@@ -924,10 +930,10 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             bf16x4 pq;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p = __builtin_amdgcn_exp2f(s[c][reg] - lse2[reg]);          // P * scale / (1-p)
-                float dpe = dp[c][reg];
-                if (DROP) dpe = drop_keep16(hw, reg, a.drop_thr, thr_hi) ? dpe : 0.f;
-                db[reg] = f2bf(p * (dpe - dl[reg]));
+                const float p = __builtin_amdgcn_exp2f(s[c][reg]);          // P * scale / (1-p)
+                float dpe = dp[c][reg];                                       // dP - delta (1-p)
+                if (DROP) dpe = drop_keep16(hw, reg, a.drop_thr, thr_hi) ? dpe : ndl[reg];
+                db[reg] = f2bf(p * dpe);
                 pq[reg] = f2bf(p);
             }
             // the key-stationary kernel re-reads P instead of recomputing it (block of 16 rows x 64 keys, P^T image order)
@@ -938,7 +944,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             // by distance: (row 4g+reg, jj = 16c + r16) -> ring column (i + M - j0 - jj) & 127
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
-                myS[(4 * g + reg) * SPITCH + ((dcol0 + reg - 16 * c) & (SRING - 1))] = db[reg];
+                ((LDS_AS bf16*)(size_t)(((unsigned)(dcolb + 2 * reg - 32 * c) & 0xFEu) | sbase))[128 * reg] = db[reg];
         }
         __builtin_amdgcn_wave_barrier();
         // flush: row r (distance dl = i + M - j0 at jj = 0) completed the aligned chunks 8c in [dl - 63, dl]
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int c = c0 + 4 * n;
-                const bf16x8 v8 = *(const bf16x8*)(myS + (lane >> 2) * SPITCH + ((8 * c) & (SRING - 1)));
+                const bf16x8 v8 = *(const bf16x8*)(myS + (lane >> 2) * SPITCH + ((8 * c + 32 * (lane >> 4)) & (SRING - 1)));
                 unsigned off = a.dsk_tiled ? fl_row + (((unsigned)(c >> 4) << 13) + (unsigned)((8 * c) & 127)) * 2u
                                            : fl_row + (unsigned)(8 * c) * 2u;
                 if (!(fl_i < T && c >= 0 && 8 * c <= dl0)) off = 0x80000000u;
