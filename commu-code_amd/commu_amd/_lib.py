@@ -43,6 +43,7 @@ class TnProblem(C.Structure):
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p
 PROTOTYPES = {
     "commu_gemm_nt_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, C.c_uint, c_f, c_f, c_p],
+    "commu_gemm_nt_signbits_words": [c_i, c_i, c_i, c_i, c_i, c_i],
     "commu_gemm_nt_ln_bf16": [c_p, c_i, c_p, c_p, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p],
     "commu_gemm_tn_bf16": [c_p, c_i, c_p, c_i, c_p, c_i, c_z, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_gemm_nt_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_i, c_i,
@@ -100,9 +101,10 @@ PROTOTYPES = {
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_hip_version": [],
 }
-_RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong}
+_RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
+            "commu_gemm_nt_signbits_words": C.c_longlong}
 _NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
-            "commu_forcing_state_ints", "commu_attn_p_scratch_elems"}
+            "commu_forcing_state_ints", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words"}
 
 _lib = None
 

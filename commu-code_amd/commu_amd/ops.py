@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import AttnBwdDesc, AttnDesc, CommuHipError, call
 
-EPI_BIAS, EPI_RELU, EPI_RESID, EPI_RELUMASK, EPI_OUT_F32, EPI_DROPOUT = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RELU, EPI_RESID, EPI_RELUMASK, EPI_OUT_F32, EPI_DROPOUT, EPI_SIGNBITS_OUT, EPI_RELUBITS = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def site_seed(base_seed: int, site: int) -> int:
@@ -110,10 +110,19 @@ def _rowmajor2d(t: torch.Tensor, name: str):
     return t.stride(0)
 
 
+def signbits_words(M, N, K, lda=None, ldb=None, ldc=None):
+    """32-bit words of the sign-bit buffer of an M x N GEMM output (gemm_nt sign_bits_out / relu_bits); 0 when the shape
+    does not take the one-bit ReLU mask (then the bf16 relu_mask is the path)."""
+    return int(call("commu_gemm_nt_signbits_words", M, N, K, K if lda is None else lda, K if ldb is None else ldb,
+                    N if ldc is None else ldc))
+
+
 def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None, out_f32=False,
-            drop_p=0.0, drop_seed=0, mask_scale=1.0):
+            drop_p=0.0, drop_seed=0, mask_scale=1.0, sign_bits_out=None, relu_bits=None):
     """out[M,N] = A[M,K] @ B[N,K]^T with the fused epilogue bias -> relu -> dropout -> +resid ->
-    relu-mask (kept values * mask_scale).  A, B bf16."""
+    relu-mask (kept values * mask_scale).  A, B bf16.
+    sign_bits_out (int32 [signbits_words]): receives one bit per output, (out > 0); relu_bits: such a buffer from a GEMM
+    with the same M x N, used instead of relu_mask (out = bit ? out * mask_scale : 0) -- 1/16 of the mask's bytes."""
     lda, ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
     M, K = A.shape
     N = B.shape[0]
@@ -137,6 +146,15 @@ def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None
         flags |= EPI_OUT_F32
     if drop_p > 0:
         flags |= EPI_DROPOUT
+    if sign_bits_out is not None or relu_bits is not None:
+        bits = sign_bits_out if sign_bits_out is not None else relu_bits
+        assert relu_mask is None and not (sign_bits_out is not None and relu_bits is not None)
+        assert bits.dtype == torch.int32 and bits.is_contiguous() and bits.numel() * 32 == M * N
+        flags |= EPI_SIGNBITS_OUT if sign_bits_out is not None else EPI_RELUBITS
+        relu_mask = bits          # (the C entry point takes the word buffer in the relu_mask argument)
+        call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid), 0, _p(bits), 0,
+             flags, int(drop_seed), float(drop_p), float(mask_scale), _s())
+        return out
     call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid),
          0 if resid is None else _rowmajor2d(resid, "resid"), _p(relu_mask),
          0 if relu_mask is None else _rowmajor2d(relu_mask, "relu_mask"), flags, int(drop_seed), float(drop_p),

@@ -614,6 +614,15 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
                           hipStream_t stream, const SkinnyLN* ln = nullptr) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (K <= 0 || (K % 32) != 0 || (lda % 8) || (ldb % 8) || (ldc % 4)) return -22;
+    if (flags & (COMMU_EPI_SIGNBITS_OUT | COMMU_EPI_RELUBITS)) {
+        // one bit per output instead of the bf16 ReLU mask: the eight-phase kernel's pipelined epilogue only
+        if (batch != 1 || ln != nullptr || relu_mask == nullptr || !gemm8_nt_bits_eligible(M, N, K, lda, ldb, ldc, flags))
+            return -22;
+        G8Args g8{(const bf16*)A, (const bf16*)B, C, lda, ldb, ldc, M, N, K, (M + 255) / 256, (N + 255) / 256,
+                  bias, nullptr, 0, (const bf16*)relu_mask, 0, flags, drop_seed,
+                  (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0), 1.f / (1.f - drop_p), mask_scale, 0, 0};
+        return launch_gemm8_nt(g8, stream);
+    }
     const bool skinny = M <= 64 && batch == 1 && bs.tri_B == 0 && (K % 128) == 0 && K <= 1024 && N >= 32 &&
                         !(flags & (COMMU_EPI_DROPOUT | COMMU_EPI_RELUMASK));
     if (ln != nullptr && !skinny) return -22;          // the LayerNorm-fused form exists for the decode step only
@@ -709,6 +718,11 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
 #undef NT_LAUNCH
     COMMU_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" long long commu_gemm_nt_signbits_words(int M, int N, int K, int lda, int ldb, int ldc) {
+    if (M <= 0 || N <= 0 || !gemm8_nt_bits_eligible(M, N, K, lda, ldb, ldc, 0)) return 0;
+    return (long long)M * N / 32;
 }
 
 extern "C" int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,

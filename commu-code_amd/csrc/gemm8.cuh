@@ -21,6 +21,8 @@ struct G8Args {
 // true when the 8-phase NT kernel takes this problem (large M, K % 64 == 0, 32-bit buffer offsets)
 bool gemm8_nt_eligible(int M, int N, int K, int lda, int ldb, int batch, int tri_B, int flags);
 int launch_gemm8_nt(const G8Args& a, hipStream_t stream);
+// sign-bit epilogues (COMMU_EPI_SIGNBITS_OUT / COMMU_EPI_RELUBITS; G8Args.rmask is the word buffer): every wave interior
+bool gemm8_nt_bits_eligible(int M, int N, int K, int lda, int ldb, int ldc, int flags);
 
 // ---- grouped TN (weight gradients): out_p[n, k] = sum_m A_p[m, n] * B_p[m, k] for up to 8 problems that share M
 struct Tn8Prob {

@@ -37,6 +37,12 @@ __device__ __forceinline__ void dma16(srd_t srd, unsigned voff, unsigned soff, u
                  :: "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
+// the same with 4 bytes per lane: global (srd base + voff[lane]) -> LDS (lds_dst + 4 * lane)
+__device__ __forceinline__ void dma4(srd_t srd, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(srd) : "memory");
+}
+
 // SRD over rows [row0, rows_total) of a row-major bf16 matrix with K columns: rows >= rows_total lie beyond
 // num_records and read as zero (the K offset travels in soffset; gfx950 range-checks voffset + soffset).
 __device__ __forceinline__ srd_t mk_srd(const bf16* base, int row0, int rows_total, int ld, int K) {
@@ -179,11 +185,12 @@ __device__ __forceinline__ bool g8_interior(const G8Args& a, int mbase, int nbas
     return (mbase + 128 <= a.M) && (nbase + 64 <= a.N) && (a.ldc % 8) == 0;
 }
 
-template <bool OUT_F32, int J, int XH>
+template <bool OUT_F32, int J, int XH, int BITS = 0>
 __device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc)[4][8], const float (&bv)[8], int mbase,
-                                         int nbase, int r16, int g) {
+                                         int nbase, int r16, int g, unsigned* bits_out = nullptr, unsigned bits_in = 0u) {
     const int N = a.N;
     const int n = nbase + 32 * J + 8 * g;
+    unsigned word = 0u;          // BITS 1: (C > 0) of this lane's 32 outputs of the quadrant, bit 8 m4 + e
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
         const int mi = 4 * XH + m4;
@@ -204,6 +211,13 @@ __device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = mix32k(i0 + (unsigned)e, key) >= a.drop_thr ? v[e] * a.drop_scale : 0.f;
         }
+        if (BITS == 2) {          // ReLU backward: bit ? C * mask_scale : 0  (sign-extended bit AND-ed onto the product)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int keep = __builtin_amdgcn_sbfe((int)bits_in, 8 * m4 + e, 1);
+                v[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[e] * a.mask_scale) & keep);
+            }
+        }
         if (OUT_F32) {
             float* C = (float*)a.C + (size_t)m * a.ldc + n;
             *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
@@ -213,16 +227,23 @@ __device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
             st_bf16x8((bf16*)a.C + (size_t)m * a.ldc + n, o);
+            if (BITS == 1) {          // what the NEXT reader of C sees as > 0: the rounded value
+#pragma unroll
+                for (int e = 0; e < 8; ++e) word |= (bf2f(o[e]) > 0.f ? 1u : 0u) << (8 * m4 + e);
+            }
         }
         acc[2 * J][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[2 * J + 1][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (BITS == 1) *bits_out = word;
 }
 
-// ABL (profiling only, COMMU_GEMM8_ABL): 1 = no MFMA, 2 = no staging after the prologue, 3 = no output stores
 // PIPE: the finished tile of an interior wave is written during the next tile's first K-tile (g8_drain; epilogues without an
 // auxiliary operand) instead of in one burst
-template <bool OUT_F32, int ABL = 0, bool PIPE = false>
+// (PIPE 2: + one bit per output, (C > 0), to the word buffer a.rmask; PIPE 3: ReLU backward from such a buffer -- the
+//  launcher guarantees that every wave is interior.  Word of (tile, wave, quadrant q in phase order, lane):
+//  ((tile * 8 + wave) * 4 + q) * 64 + lane.)
+template <bool OUT_F32, int ABL = 0, int PIPE = 0>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES + 8 * 4096];          // + edge-tile scratch
     const int tid = threadIdx.x, lane = tid & 63;
@@ -309,6 +330,12 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
     bool pend = false;
     int pmb = 0, pnb = 0, bnb = -1;
     const int pflags = a.flags;
+    constexpr int BITS = PIPE == 2 ? 1 : (PIPE == 3 ? 2 : 0);
+    unsigned* pbits = nullptr;          // PIPE 2 / 3: this lane's word of quadrant 0 of the pending tile (quadrant q: + 64 q)
+    // PIPE 3: the pending tile's four words per lane come to this wave's (otherwise unused) edge scratch by LDS-DMA at the end
+    // of the tile, [q][lane] -- not to registers: the compiler may copy an asm-loaded register before the data has landed
+    const LDS_AS unsigned* rbl = (const LDS_AS unsigned*)(smem + 2 * BUF_BYTES + w * 4096) + lane;
+    const srd_t srdBits = __builtin_amdgcn_make_buffer_rsrc((void*)a.rmask, 0, PIPE == 3 ? (int)((size_t)a.M * a.N / 8) : 0, 0x00020000);
     float bvl[2][8];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -376,7 +403,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             xf[mi][1] = G8_FRAG(pbo + Q_XLO * HT_BYTES + xo1 + mi * 2048);
         }
         if (v1) stage(Q_WLO, c1, pb ^ 1);
-        if (PIPE && pend) g8_drain<OUT_F32, 0, 0>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
+        if (PIPE == 3 && pend) {          // the pending tile's sign words: older than this phase's Wlo pieces only
+            if (v1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (PIPE && pend) g8_drain<OUT_F32, 0, 0, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits + 0, PIPE == 3 ? rbl[0] : 0u);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             wf[ni][1] = G8_FRAG(pbo + Q_WHI * HT_BYTES + wo1 + ni * 2048);
         }
         if (v2) stage(Q_XLO, c2, pb);
-        if (PIPE && pend) g8_drain<OUT_F32, 1, 0>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
+        if (PIPE && pend) g8_drain<OUT_F32, 1, 0, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 64, PIPE == 3 ? rbl[64] : 0u);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -414,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             xf[mi][1] = G8_FRAG(pbo + Q_XHI * HT_BYTES + xo1 + mi * 2048);
         }
         if (v2) stage(Q_WHI, c2, pb);
-        if (PIPE && pend) g8_drain<OUT_F32, 1, 1>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
+        if (PIPE && pend) g8_drain<OUT_F32, 1, 1, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 128, PIPE == 3 ? rbl[128] : 0u);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -435,11 +466,13 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
         }
         if (v2) stage(Q_XHI, c2, pb);
         if (PIPE && pend) {
-            g8_drain<OUT_F32, 0, 1>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
+            g8_drain<OUT_F32, 0, 1, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits + 192, PIPE == 3 ? rbl[192] : 0u);
             // (vmcnt retires in order: the K-tile needed next was complete with phase 1's Wlo pieces; younger than those are the
-            //  three half-tiles of phases 2-4 and the 4 x 4 (fp32 output: 4 x 8) output stores of the four drains)
+            //  three half-tiles of phases 2-4 and the 4 x 4 (fp32 output: 4 x 8; with sign words: 4 x 5) output stores of the
+            //  four drains)
             if (!v2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (OUT_F32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+            else if (PIPE == 2) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
             pend = false;
         } else if (v2) {
@@ -466,6 +499,16 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
                 pmb = mb;
                 pnb = nb;
                 if (PIPE) load_bias(nb);
+                if (PIPE >= 2) {
+                    const int lid = (c0.m0 >> 8) * a.tiles_n + (c0.n0 >> 8);
+                    pbits = (unsigned*)a.rmask + ((size_t)(lid * 8 + w) * 4) * 64 + lane;
+                    if (PIPE == 3) {
+                        const unsigned vo = (unsigned)(((lid * 8 + w) * 4) * 64 + lane) * 4u;
+                        const unsigned dst = lds0 + 2 * BUF_BYTES + w * 4096;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dma4(srdBits, vo + 256u * q, dst + 256u * q);
+                    }
+                }
             } else {
                 g8_store<OUT_F32>(a, acc, mb, nb, r16, g, (LDS_AS float*)(smem + 2 * BUF_BYTES + w * 4096), lane);
 #pragma unroll
@@ -480,10 +523,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
         pb ^= 1;
     }
     if (PIPE && pend) {          // the last tile of this workgroup
-        g8_drain<OUT_F32, 0, 0>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
-        g8_drain<OUT_F32, 1, 0>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
-        g8_drain<OUT_F32, 1, 1>(a, pflags, acc, bvl[1], pmb, pnb, r16, g);
-        g8_drain<OUT_F32, 0, 1>(a, pflags, acc, bvl[0], pmb, pnb, r16, g);
+        if (PIPE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g8_drain<OUT_F32, 0, 0, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits, PIPE == 3 ? rbl[0] : 0u);
+        g8_drain<OUT_F32, 1, 0, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 64, PIPE == 3 ? rbl[64] : 0u);
+        g8_drain<OUT_F32, 1, 1, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 128, PIPE == 3 ? rbl[128] : 0u);
+        g8_drain<OUT_F32, 0, 1, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits + 192, PIPE == 3 ? rbl[192] : 0u);
     }
     if (wr == 0) G8_BAR();          // pairs with the stagger barrier of the second wave row
 #undef G8_FRAG
@@ -725,6 +769,15 @@ bool gemm8_nt_eligible(int M, int N, int K, int lda, int ldb, int batch, int tri
     return true;
 }
 
+bool gemm8_nt_bits_eligible(int M, int N, int K, int lda, int ldb, int ldc, int flags) {
+    // every wave of every tile takes the pipelined (interior) epilogue: whole tiles, 16-byte aligned output rows, bf16 output,
+    // no auxiliary operand; ALWAYS in the environment (tests) lifts the 256-tile minimum of gemm8_nt_eligible
+    if ((M % 256) || (N % 256) || (ldc % 8)) return false;
+    if (flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK | COMMU_EPI_OUT_F32)) return false;
+    if ((flags & COMMU_EPI_SIGNBITS_OUT) && (flags & COMMU_EPI_RELUBITS)) return false;
+    return gemm8_nt_eligible(M, N, K, lda, ldb, 1, 0, flags);
+}
+
 int launch_gemm8_nt(const G8Args& a_in, hipStream_t stream) {
     const G8Args& a0 = a_in;
     const int ntiles = a0.tiles_m * a0.tiles_n;
@@ -744,8 +797,12 @@ int launch_gemm8_nt(const G8Args& a_in, hipStream_t stream) {
     const bool pipe = getenv("COMMU_GEMM8_NOPIPE") == nullptr;
     if (a.flags & COMMU_EPI_OUT_F32) {
         G8_LAUNCH(true, 0);
+    } else if (a.flags & COMMU_EPI_SIGNBITS_OUT) {
+        COMMU_LAUNCH((gemm_nt8_kernel<false, 0, 2>), dim3(grid), dim3(512), 0, stream, a);
+    } else if (a.flags & COMMU_EPI_RELUBITS) {
+        COMMU_LAUNCH((gemm_nt8_kernel<false, 0, 3>), dim3(grid), dim3(512), 0, stream, a);
     } else if (pipe && abl == 0 && !(a.flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK))) {
-        COMMU_LAUNCH((gemm_nt8_kernel<false, 0, true>), dim3(grid), dim3(512), 0, stream, a);
+        COMMU_LAUNCH((gemm_nt8_kernel<false, 0, 1>), dim3(grid), dim3(512), 0, stream, a);
     } else {
         switch (abl) {
             case 1: G8_LAUNCH(false, 1); break;

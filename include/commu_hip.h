@@ -33,8 +33,16 @@ enum {
     COMMU_EPI_RESID = 4,     /* C += resid[m, n] (bf16)         (w + attn_out / inp + core_out)    */
     COMMU_EPI_RELUMASK = 8,  /* C = relu_mask[m,n] > 0 ? C : 0  (ReLU backward)                    */
     COMMU_EPI_OUT_F32 = 16,  /* C is fp32 (default bf16)                                           */
-    COMMU_EPI_DROPOUT = 32   /* C = keep(drop_seed, m*N+n) ? C/(1-p) : 0  (nn.Dropout, model.py:166,168,210) */
+    COMMU_EPI_DROPOUT = 32,  /* C = keep(drop_seed, m*N+n) ? C/(1-p) : 0  (nn.Dropout, model.py:166,168,210) */
+    /* ReLU backward from ONE BIT per element instead of the bf16 activations (1/16 of the bytes).  SIGNBITS_OUT: the
+     * `relu_mask` argument is an OUTPUT of commu_gemm_nt_signbits_words(M, N, K) 32-bit words receiving (C > 0) after the
+     * epilogue, in a layout private to the kernel; RELUBITS: `relu_mask` is such a buffer written by a GEMM of the same
+     * M x N, C = bit ? C * mask_scale : 0.  Only shapes with a non-zero word count; no RESID / RELUMASK / OUT_F32. */
+    COMMU_EPI_SIGNBITS_OUT = 64,
+    COMMU_EPI_RELUBITS = 128
 };
+/* words of the sign-bit buffer for an M x N output (0: this shape / K does not take the flags above) */
+long long commu_gemm_nt_signbits_words(int M, int N, int K, int lda, int ldb, int ldc);
 /* C[M,N] = A[M,K] . B[N,K]^T with fused epilogue, applied in this order: bias, relu, dropout, resid,
  * relu-mask (kept values times mask_scale).  K % 32 == 0, lda/ldb % 8 == 0, ldc % 4 == 0. */
 int commu_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N,

@@ -59,3 +59,19 @@ for N, K in ((512, 512), (512, 1024), (1536, 512), (512, 1536)):
     os.environ.pop("COMMU_GEMM8_NOPIPE", None)
     t1 = timeit(lambda: ops.gemm_nt(x, w, out=y2))
     print(f"(65536,{N},{K}) plain   burst {t0:7.1f} us   pipelined {t1:7.1f} us   equal {bool(torch.equal(y, y2))}")
+# ReLU backward: bf16 mask against one bit per element (shape of dhid = dz . W2: M x 1024, K = 512)
+os.environ.pop("COMMU_GEMM8_NOPIPE", None)
+x = torch.randn(M, 512, device=dev).bfloat16()
+w = torch.randn(1024, 512, device=dev).bfloat16()
+y = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
+y2 = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
+b = torch.randn(1024, device=dev)
+bits = torch.empty(M * 1024 // 32, device=dev, dtype=torch.int32)
+kw = dict(bias=b, relu=True, drop_p=0.1, drop_seed=3)
+t0 = timeit(lambda: ops.gemm_nt(x, w, out=y, **kw))
+t1 = timeit(lambda: ops.gemm_nt(x, w, out=y2, sign_bits_out=bits, **kw))
+print(f"forward bias+relu+dropout {t0:7.1f} us   + sign bits out {t1:7.1f} us   equal {bool(torch.equal(y, y2))}")
+hid = y.clone()
+t0 = timeit(lambda: ops.gemm_nt(x, w, out=y, relu_mask=hid, mask_scale=1.1))
+t1 = timeit(lambda: ops.gemm_nt(x, w, out=y2, relu_bits=bits, mask_scale=1.1))
+print(f"backward relu_mask (bf16) {t0:7.1f} us   relu_bits {t1:7.1f} us   equal {bool(torch.equal(y, y2))}")

@@ -175,6 +175,32 @@ def test_gemm_nt_eight_phase_pipelined_epilogue(M, N, K, grid, monkeypatch):
     assert relerr(pipe[2], torch.relu(ref + bias) * keep / 0.9) < BF16_TOL
 
 
+@pytest.mark.parametrize("grid", [0, 3])
+@pytest.mark.parametrize("M,N,K,K2", [(2048, 512, 128, 256), (1024, 1024, 512, 192)])
+def test_gemm_nt_relu_sign_bits(M, N, K, K2, grid, monkeypatch):
+    """ReLU backward from one bit per element: the forward GEMM's epilogue writes (out > 0) into a word buffer, the
+    backward GEMM (same M x N output) reads it instead of the bf16 activations.  Bit-identical to the relu_mask path."""
+    o = ops()
+    monkeypatch.setenv("COMMU_GEMM8_ALWAYS", "1")
+    if grid:
+        monkeypatch.setenv("COMMU_GEMM8_GRID", str(grid))
+    assert o.signbits_words(2300, 729, 128) == 0 and o.signbits_words(M, N, K) == M * N // 32
+    A, W1, b1 = bf(rnd(M, K, seed=41)).to(DEV), bf(rnd(N, K, seed=42)).to(DEV), rnd(N, seed=43).to(DEV)
+    G, W2t = bf(rnd(M, K2, seed=44)).to(DEV), bf(rnd(N, K2, seed=45)).to(DEV)
+    kw = dict(bias=b1, relu=True, drop_p=0.1, drop_seed=5)
+    hid = o.gemm_nt(A, W1, **kw)
+    bits = torch.full((M * N // 32,), -1, device=DEV, dtype=torch.int32)
+    hid2 = o.gemm_nt(A, W1, sign_bits_out=bits, **kw)
+    assert torch.equal(hid, hid2)
+    assert int((hid > 0).sum()) == sum(bin(int(x) & 0xFFFFFFFF).count("1") for x in bits[:4096].tolist()) \
+        + int(sum(bin(int(x) & 0xFFFFFFFF).count("1") for x in bits[4096:].tolist()))
+    ref = o.gemm_nt(G, W2t, relu_mask=hid, mask_scale=1.0 / 0.9)
+    got = o.gemm_nt(G, W2t, relu_bits=bits, mask_scale=1.0 / 0.9)
+    assert torch.equal(ref, got)
+    full = (G.float() @ W2t.float().t()) * (hid.float() > 0) / 0.9
+    assert relerr(got, full.cpu()) < BF16_TOL
+
+
 def test_gemm_nt_eight_phase_asymmetric_identity(monkeypatch):
     """A = [I; 0...] pattern with an asymmetric B: catches transposed / permuted C writes of the 8-phase kernel."""
     o = ops()

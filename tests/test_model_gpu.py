@@ -429,3 +429,30 @@ def test_generate_cli_from_a_reference_checkpoint(golden_dir, tmp_path):
     out = json.load(open(tmp_path / "out" / "sequences.json"))
     assert out["encoded_meta"] == [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
     assert out["sequences"] == seqs and len(seqs) <= 2          # a random model rarely passes both validators
+
+
+@pytest.mark.gpu
+def test_relu_sign_bits_option_gives_identical_gradients(monkeypatch):
+    """model.relu_sign_bits (opt-in): the FF ReLU backward reads one bit per element written by the forward GEMM instead of
+    the bf16 activations -- same loss, same gradients (dropout on, same seeds)."""
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import build_model
+    monkeypatch.setenv("COMMU_GEMM8_ALWAYS", "1")          # small test shape: 1024 x 512 outputs are 8 tiles
+    dev = torch.device("cuda", 0)
+    cfg = get_cfg(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=64, mem_length=0, batch_size=16,
+                  batch_chunk=1, dropout=0.1, attention_dropout=0.1)
+    d, t, r, _ = synthetic_batch(64, 16, dev, seed=3)
+    out = []
+    for bits in (False, True):
+        model = build_model(cfg, BaseVocab(), dev, seed=5)
+        model.train()
+        model.relu_sign_bits = bits
+        torch.manual_seed(11)
+        loss, _ = model(d, t, r, None)
+        loss.float().mean().backward()
+        out.append((loss.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]))
+    assert torch.equal(out[0][0], out[1][0])
+    for ga, gb in zip(out[0][1], out[1][1]):          # (bias / LayerNorm-parameter column sums use fp32 atomics: order noise)
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12
+    assert any(float(g.abs().max()) > 0 for g in out[0][1])
