@@ -530,7 +530,9 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     # (fresh, uninitialised scratch) or the caller keeps ONE zero-initialised scratch per shape alive
     # (`scratch` dict, used by the model): nothing ever writes beyond the triangle, so it stays zero -- no 1 GB
     # fill per layer and no wedge.
-    band = (not same_length) and reset is None
+    # (reset_mems: the kernel writes zeros over the distances of the memory tiles a fresh sequence skips, so the band
+    #  structure -- and the persistent scratch -- also hold for the training configurations with XL memory)
+    band = not same_length
     key = (T, M, B, H, ld_dsk, str(dev))
     if band and scratch is not None and not POISON_SCRATCH:
         if scratch.get("key") != key:

@@ -874,6 +874,19 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         const unsigned m = (unsigned)min(fl_i, T - 1) * (unsigned)B + (unsigned)b;
         fl_row = a.dsk_tiled ? (((m >> 6) * (unsigned)(a.ld_dsk >> 7)) << 14) + ((m & 63u) << 8) : m * (unsigned)a.ld_dsk * 2u;
     }
+    if (rst && jt_lo > 0) {
+        // a sequence that starts here (reset_mems) does not see the memory: its key tiles below jt_lo are skipped -- their
+        // distances (dtop, i + M] of every row must still READ as zero for the band consumers, and the scratch is re-used
+        // between layers and steps, so they are written: whole 16-byte chunks above the one the first tile completes
+        const int dtop = fl_i + M - 64 * jt_lo, clast = (fl_i + M) >> 3;
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        for (int c = (dtop >> 3) + 1 + (lane & 3); c <= ((iw_hi + M) >> 3); c += 4) {
+            unsigned off = a.dsk_tiled ? fl_row + (((unsigned)(c >> 4) << 13) + (unsigned)((8 * c) & 127)) * 2u
+                                       : fl_row + (unsigned)(8 * c) * 2u;
+            if (!(fl_i < T && c <= clast)) off = 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(z4, srdD, (int)off, 0, 0);
+        }
+    }
     for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
         const int j0 = jt * 64;
         if (jt < jt_hi) issue(jt + 1);
@@ -1505,7 +1518,7 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     a.dsk_tiled = e->dsk_tiled;
     a.pbuf = (bf16*)e->p_scratch;
     if (e->p_scratch != nullptr && d->DH != 64) return -22;
-    if (a.dsk_wedge > 0 && (d->same_length || d->reset != nullptr)) return -22;
+    if (a.dsk_wedge > 0 && d->same_length) return -22;
     if ((e->ld_dsk % 8) || (a.dsk_tiled && ((e->ld_dsk % 128) || (((long long)d->T * d->B) % 64)))) return -22;
     if (e->du_rows != (d->T + 63) / 64) return -22;
     if ((size_t)d->T * d->B * e->ld_dsk * 2 >= 0x7FFF0000ull) return -22;          // the flush addresses one head's block with 32-bit offsets
