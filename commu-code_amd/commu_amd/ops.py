@@ -322,6 +322,13 @@ def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0, ld=None):
 
 def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0):
     V, D = dE.shape
+    nch = call("commu_embed_bwd_chunks", tok.numel(), D, V) if dE.is_contiguous() else 0
+    if nch > 0:          # training-step sizes: per-chunk LDS tables -> slabs -> one reduction into the gradient
+        slabs = torch.empty(nch, V, D, device=dE.device, dtype=F32)
+        call("commu_embed_bwd_slabs", _p(tok), _p(dX), dX.stride(0), _p(slabs), nch, tok.numel(), D, V, int(drop_seed),
+             float(drop_p), _s())
+        reduce_slabs(dE, slabs, V * D, nch, V * D, accumulate, alpha=math.sqrt(D))
+        return dE
     call("commu_embed_bwd", _p(tok), _p(dX), dX.stride(0), _p(dE), tok.numel(), D, V, math.sqrt(D),
          1 if accumulate else 0, int(drop_seed), float(drop_p), _s())
     return dE

@@ -79,6 +79,44 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     }
 }
 
+// The same sums for the training step (65 536 tokens): workgroup (column slice of 32, token chunk) accumulates ITS tokens'
+// rows into an LDS table [V][32] (fp32 LDS atomics: the order of the additions inside a workgroup is not fixed) and writes
+// the table as one slab [chunk][V][D]; commu_reduce_slabs_f32 folds the slabs into the gradient.  Every dX byte is read
+// once; the kernel above reads the token list once per vocabulary row (382 MB at V = 729) and one row at a time.
+constexpr int EMB_VMAX = 768, EMB_SLICE = 32;
+__global__ __launch_bounds__(256) void embed_bwd_slab_kernel(
+    const int64_t* __restrict__ tok, const bf16* __restrict__ dX, int ldx, float* __restrict__ slabs, int ntok, int D,
+    int V, int tok_per_chunk, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
+    __shared__ float tab[EMB_VMAX * EMB_SLICE];
+    const int tid = threadIdx.x, c0 = blockIdx.x * EMB_SLICE, chunk = blockIdx.y;
+    for (int i = tid; i < V * EMB_SLICE; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int sub = tid & 3, col = c0 + 8 * sub;          // this thread's 8 columns
+    const int mbeg = chunk * tok_per_chunk, mend = min(ntok, mbeg + tok_per_chunk);
+    const unsigned key = mix32(drop_seed);
+    if (col < D) {
+        for (int m = mbeg + (tid >> 2); m < mend; m += 64) {
+            const long long v = tok[m];
+            if (v < 0 || v >= V) continue;
+            const bf16x8 x = ld_bf16x8(dX + (size_t)m * ldx + col);          // (row padding beyond D is readable: ldx >= D8)
+            float* t = tab + (int)v * EMB_SLICE + 8 * sub;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (col + e >= D) break;
+                float f = bf2f(x[e]);
+                if (drop_thr) f = mix32k((unsigned)m * (unsigned)D + (unsigned)(col + e), key) >= drop_thr ? f * drop_scale : 0.f;
+                atomicAdd(t + e, f);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = slabs + (size_t)chunk * V * D;
+    for (int i = tid; i < V * EMB_SLICE; i += 256) {
+        const int v = i >> 5, c = c0 + (i & 31);
+        if (c < D) out[(size_t)v * D + c] = tab[i];
+    }
+}
+
 // K2: sinusoid table indexed by DISTANCE d (pos = d): out[d] = [sin(d f) | cos(d f)]
 // (commu/model/model.py:142-147; the reference's row k of pos_emb is distance klen-1-k).
 __global__ void posemb_kernel(const float* __restrict__ inv_freq, bf16* __restrict__ out, int ld,
@@ -604,6 +642,22 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
     if (D > 1024) return -22;
     COMMU_LAUNCH(embed_bwd_kernel, dim3(V), dim3(256), 0, stream, tok, (const bf16*)dX, ldx, dE,
                        ntok, D, scale, accumulate, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_embed_bwd_chunks(int ntok, int D, int V) {
+    if (V > EMB_VMAX || ntok < 4096) return 0;          // (small inputs: the one-workgroup-per-row kernel)
+    int n = (ntok + 4095) / 4096;
+    return n > 16 ? 16 : n;
+}
+
+extern "C" int commu_embed_bwd_slabs(const int64_t* tok, const void* dX, int ldx, float* slabs, int nchunks, int ntok,
+                                     int D, int V, unsigned drop_seed, float drop_p, hipStream_t stream) {
+    if (V > EMB_VMAX || nchunks <= 0 || ldx < ((D + 7) & ~7) || (ldx % 8)) return -22;
+    const int tpc = (((ntok + nchunks - 1) / nchunks) + 63) / 64 * 64;
+    COMMU_LAUNCH(embed_bwd_slab_kernel, dim3((D + EMB_SLICE - 1) / EMB_SLICE, nchunks), dim3(256), 0, stream, tok,
+                 (const bf16*)dX, ldx, slabs, ntok, D, V, tpc, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }

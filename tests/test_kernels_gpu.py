@@ -303,6 +303,29 @@ def test_embed_fwd_bwd():
     assert relerr(dE, ref) < 1e-5
 
 
+@pytest.mark.parametrize("D,ld", [(512, 512), (500, 512), (128, 136)])
+def test_embed_bwd_token_chunks(D, ld):
+    """Training-step sizes take the chunked kernel (LDS tables -> slabs -> reduce): against index_add, with dropout,
+    collisions, ids outside the vocabulary (ignored) and a row stride wider than D."""
+    o = ops()
+    V, n = 729, 9000
+    tok = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(13))
+    tok[:300] = 7
+    tok[300:310] = V + 5          # outside the vocabulary: contribute nothing
+    tok[310:320] = -1
+    dX = torch.zeros(n, ld, dtype=torch.bfloat16)
+    dX[:, :D] = bf(rnd(n, D, seed=14))
+    seed, p = 991, 0.1
+    keep = o.dropout_keep_mask(seed, n * D, p).view(n, D).float()
+    ok = ((tok >= 0) & (tok < V))
+    ref = torch.zeros(V, D).index_add_(0, tok[ok], (dX[:, :D].float() * keep / (1 - p))[ok]) * math.sqrt(D)
+    dE = torch.ones(V, D, device=DEV)
+    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], dE, accumulate=True, drop_p=p, drop_seed=seed)
+    assert relerr(dE - 1, ref) < 1e-5
+    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], dE, accumulate=False)
+    assert relerr(dE, torch.zeros(V, D).index_add_(0, tok[ok], dX[:, :D].float()[ok]) * math.sqrt(D)) < 1e-5
+
+
 def test_out_of_range_ids_poison_the_loss():
     """A token / target id outside [0, V) (the reference raises IndexError) must neither read out of bounds nor
     pass silently: the embedding row and the row's nll come out NaN, the other rows are untouched."""
