@@ -28,7 +28,7 @@ class AttnDesc(C.Structure):
 class AttnBwdDesc(C.Structure):
     _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
                 ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
-                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i), ("p_scratch", c_p)]
+                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i), ("p_scratch", c_p), ("o", c_p)]
 
 
 class ReduceItem(C.Structure):

@@ -513,6 +513,7 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 # normalisation arithmetic cost a latency-bound skinny GEMM more than the launch they save -- so it is OFF by default.
 FUSE_DECODE_LN = False
 STORE_ATTN_P = True         # backward: bwd_q stores P for bwd_kv (d_head 64); False: both kernels recompute it
+DELTA_KERNEL = False        # tests / A-B runs: delta from commu_attn_delta instead of inside the query-stationary kernel
 NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead of commu_relattn_bwd_band
 
 
@@ -526,8 +527,11 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     qrows = call("commu_attn_bwd_qrows", T)
     QT = (T + qrows - 1) // qrows
     qu2, qv2 = qs
+    # delta[b,h,i] = sum_d o . dout: computed (and written, for the key-stationary kernel) by the query-stationary kernel
+    # from the dout fragments it holds anyway (commu_attn_bwd_desc.o); DELTA_KERNEL: the separate launch instead
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
-    call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
+    if DELTA_KERNEL or o.stride(0) != dout.stride(0):
+        call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
     # fused band pass (commu_relattn_bwd_band: dq_BD and dRd in ONE sweep over dS-by-distance) when the shape allows
     band_slabs = call("commu_attn_band_slabs", T, B) if (DH == 64 and K <= 4096 and not NO_FUSED_BAND) else 0
     ld_dsk = round_up(K, 128) if band_slabs else round_up(K, 32)
@@ -585,6 +589,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     if _os.environ.get("COMMU_ABL_DSK"):          # profiling ablation: bwd_q without its dS-by-distance stores
         e.dsk_wedge = -7
     assert dv.stride(0) == dk.stride(0)
+    if not (DELTA_KERNEL or o.stride(0) != dout.stride(0)):
+        e.o = o.data_ptr()
     call("commu_relattn_bwd_q", C.byref(d), C.byref(e), _s())
     call("commu_relattn_bwd_kv", C.byref(d), C.byref(e), _s())
     c2 = d.scale * 1.4426950408889634

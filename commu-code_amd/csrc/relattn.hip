@@ -41,6 +41,7 @@ struct AttnArgs {
     const bf16* dout;   // dO rows like out, ld_o
     const float* lse_in;
     const float* delta;
+    const bf16* o_in;   // backward: forward output (or null); bwd_q then computes delta itself and writes it to `delta`
     bf16* out;          // [T*B][ld_o]
     float* lse;         // [B][H][T]
     bf16* dq;           // [T*B][H*DH] AC part of dq
@@ -796,6 +797,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     const float dsc = DROP ? a.drop_scale : 1.f;
 
     bf16x8 qu[KS], qv[KS], dof[KS];
+    float drow = 0.f;          // a.o_in: delta of row r16 (sum over d of o . dout), in every lane of that row after the reduction
     {
         const int iq = min(i0 + 16 * w + r16, T - 1);
         const size_t off = ((size_t)iq * B + b) * HD + h * DH;
@@ -806,6 +808,19 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             qv[ks] = ld_bf16x8(a.qv2 + off + 32 * ks + 8 * g);
             dof[ks] = ld_bf16x8(dop + 32 * ks + 8 * g);
         }
+        if (a.o_in != nullptr) {
+            const bf16* op = a.o_in + ((size_t)iq * B + b) * a.ld_o + h * DH;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 of = ld_bf16x8(op + 32 * ks + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) drow += bf2f(of[e]) * bf2f(dof[ks][e]);
+            }
+            drow += __shfl_xor(drow, 16, 64);
+            drow += __shfl_xor(drow, 32, 64);
+            if (g == 0 && i0 + 16 * w + r16 < T)
+                const_cast<float*>(a.delta)[((size_t)b * a.H + h) * T + i0 + 16 * w + r16] = drow;
+        }
     }
     // -lse2 and -delta/dsc are the INITIAL values of the score / dP accumulators (the MFMA's C operand): no subtraction per element
     f32x4 nls, ndl;
@@ -815,7 +830,8 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     for (int reg = 0; reg < 4; ++reg) {
         const int i = min(i0 + 16 * w + 4 * g + reg, T - 1);
         nls[reg] = __log2f(a.scale * dsc) - a.lse_in[((size_t)b * a.H + h) * T + i] * LOG2E;
-        ndl[reg] = -a.delta[((size_t)b * a.H + h) * T + i] / dsc;
+        // (rows 4g + reg of the C layout: from the lane that holds that row)
+        ndl[reg] = -(a.o_in != nullptr ? bperm((4 * g + reg) << 2, drow) : a.delta[((size_t)b * a.H + h) * T + i]) / dsc;
         srcaddr[reg] = ((lane & 48) | ((4 * g + reg - 1 - r16) & 15)) << 2;
         lower[reg] = r16 < 4 * g + reg;
     }
@@ -1517,6 +1533,7 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     a.dsk_wedge = e->dsk_wedge;
     a.dsk_tiled = e->dsk_tiled;
     a.pbuf = (bf16*)e->p_scratch;
+    a.o_in = (const bf16*)e->o;
     if (e->p_scratch != nullptr && d->DH != 64) return -22;
     if (a.dsk_wedge > 0 && d->same_length) return -22;
     if ((e->ld_dsk % 8) || (a.dsk_tiled && ((e->ld_dsk % 128) || (((long long)d->T * d->B) % 64)))) return -22;

@@ -255,6 +255,9 @@ typedef struct commu_attn_bwd_desc {
                              the query-stationary kernel stores the probabilities it recomputes there and the
                              key-stationary kernel, which must then run AFTER it on the same stream, reads them
                              back instead of recomputing (q+u).k, the band product / rel-shift, masks and exp */
+    const void* o;        /* NULL, or the forward output (bf16 [T*B][ld_o]): the query-stationary kernel then computes
+                             delta[b,h,i] = sum_d o . dout itself (commu_attn_delta is not needed) and WRITES it to
+                             `delta` for the key-stationary kernel, which must run after it on the same stream */
 } commu_attn_bwd_desc;
 long long commu_attn_p_scratch_elems(int T, int M, int B, int H);
 int commu_attn_bwd_qrows(int T);
