@@ -488,6 +488,13 @@ class MemTransformerLM(nn.Module):
         u, vb = self._uv()
         h_out = None
         kv_out = []
+        # K5 for all layers at once: r_net sees the same position table in every layer, and the bf16 copies of the layers'
+        # weights sit at a constant stride in the flat buffer -> one batched launch instead of L small ones
+        rd_all = None
+        if L > 1 and not self._padded:
+            o0, o1 = self._name_off["layers.0.dec_attn.r_net.weight"], self._name_off["layers.1.dec_attn.r_net.weight"]
+            if o0 % 8 == 0 and (o1 - o0) % 8 == 0 and Dt % 8 == 0:
+                rd_all = ops.gemm_nt_layers(pd, self._flat["bf16"][o0:], HD, Dt, o1 - o0, L)
         fp8 = bool(getattr(self, "fp8_forward", False))
         if fp8 and (self._padded or D % 128 or DI % 128 or HD % 128):
             raise CommuHipError("fp8_forward needs d_model, d_inner and n_head * d_head to be multiples of 128")
@@ -512,7 +519,7 @@ class MemTransformerLM(nn.Module):
                 ops.linear_mxfp8(h, f8["qkv"], out=qkv[M * B:])
             else:
                 ops.gemm_nt(h, w["qkv"], out=qkv[M * B:])
-            rd = ops.gemm_nt(pd, w["r"])                                         # K5
+            rd = rd_all[i] if rd_all is not None else ops.gemm_nt(pd, w["r"])    # K5
             vec, lse, qs = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
                                            T, M, B, H, DH, bool(self.same_length), int(self.mem_len),
                                            save_q=need_grad, drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale)    # K6

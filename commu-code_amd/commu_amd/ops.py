@@ -110,6 +110,19 @@ def _rowmajor2d(t: torch.Tensor, name: str):
     return t.stride(0)
 
 
+def gemm_nt_layers(A, Bflat, N, K, stride, batch, out=None):
+    """out[z] = A @ B_z^T for z < batch, B_z = Bflat[z*stride : z*stride + N*K].view(N, K): ONE launch for the same Linear
+    of every layer when its input is shared (r_net on the position table, model.py:278,313)."""
+    M = A.shape[0]
+    assert A.dtype == BF16 and Bflat.dtype == BF16 and A.shape[1] == K and Bflat.is_contiguous()
+    assert Bflat.numel() >= (batch - 1) * stride + N * K
+    if out is None:
+        out = torch.empty(batch, M, N, device=A.device, dtype=BF16)
+    call("commu_gemm_nt_bf16_batched", _p(A), _rowmajor2d(A, "A"), 0, _p(Bflat), K, stride, _p(out), N, M * N, M, N, K,
+         None, 0, 0, 0, batch, 0, 0, _s())
+    return out
+
+
 def signbits_words(M, N, K, lda=None, ldb=None, ldc=None):
     """32-bit words of the sign-bit buffer of an M x N GEMM output (gemm_nt sign_bits_out / relu_bits); 0 when the shape
     does not take the one-bit ReLU mask (then the bf16 relu_mask is the path)."""
