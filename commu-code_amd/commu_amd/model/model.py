@@ -707,6 +707,16 @@ class MemTransformerLM(nn.Module):
         def ss(site):
             return ops.site_seed(sv.seed, site)
 
+        # the embedding scatter at the end of the pass walks the tokens in sorted order: argsort + segment offsets are three
+        # small torch kernels, issued now on the second side stream
+        order_box, order_ready = {}, None
+
+        def mk_order():
+            order_box["o"] = ops.token_order(sv.tokens, V)
+        defer_light(mk_order)
+        if side2 is not None:
+            order_ready = torch.cuda.Event()
+            order_ready.record(side2)
         flush_wgrads()
         gE_done = None
         if side is not None:          # embed_bwd below accumulates into gE too: ordered after THIS launch only, not a join
@@ -718,10 +728,25 @@ class MemTransformerLM(nn.Module):
             gu_t, gvb_t = gu, gvb
             gu, gvb = torch.zeros(HD, device=dev, dtype=F32), torch.zeros(HD, device=dev, dtype=F32)
         u_k, vb_k = self._uv()
+        side_mark = [None]
+
+        def defer_last(fn):          # the last layer's dRd chain: second side stream, but AFTER everything the first side
+            if side2 is None:        # stream was given for the layers above (they all add into r_w_bias / r_r_bias)
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side2):
+                side2.wait_event(ev)
+                side2.wait_event(side_mark[0])
+                fn()
+
         for i in range(L - 1, -1, -1):
             pre = f"layers.{i}."
             lay = self.layers[i]
             s0 = 16 + 4 * i
+            if i == 0 and side is not None:
+                side_mark[0] = torch.cuda.Event()
+                side_mark[0].record(side)
             dz2m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz2, part = ops.layernorm_bwd(dy, sv.z2[i], sv.mu2[i], sv.rs2[i], lay.pos_ff.layer_norm.weight,
                                           dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3))
@@ -740,11 +765,6 @@ class MemTransformerLM(nn.Module):
             wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
             defer_light(lambda dhid=dhid, pre=pre: ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,))))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
-            if i == 0:
-                # the last layer of the pass: nothing follows its weight gradients on the main stream but one GEMM and the
-                # embedding scatter, so the two large ones leave now (beside this layer's attention backward) and only
-                # o|qkv remain for the end -- the main stream waited ~0.35 ms for that tail
-                flush_wgrads()
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
                                           dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1))
@@ -754,6 +774,12 @@ class MemTransformerLM(nn.Module):
             defer_light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
                 part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)), gv(pre + "dec_attn.layer_norm.bias", (Dt,))))
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
+            last = i == 0
+            if last:
+                # the last layer of the pass: nothing follows its weight gradients on the main stream but one GEMM and the
+                # embedding scatter, so w2 | w1 | o leave now (beside this layer's attention backward) and only qkv remains
+                # for the end; its dRd chain goes to the second side stream, beside that last grouped launch
+                flush_wgrads()
             dvec = ops.gemm_nt(dz1m, sh[f"o_t{i}"])
             qkv = sv.qkv[i]
             # (the q third of the memory rows is never written and never read: memory rows have no query, their weight
@@ -766,13 +792,14 @@ class MemTransformerLM(nn.Module):
                             vb_k, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
-                            scratch=scr[i & 1], defer=defer if side is not None else None)
+                            scratch=scr[i & 1], defer=(defer_last if last else defer) if side is not None else None)
             gWr = gv(pre + "dec_attn.r_net.weight", (HDt, Dt))
             if side is None:
                 self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"))
             else:
                 keep.append(drd)
-                defer(lambda drd=drd, gWr=gWr: self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r")))
+                (defer_last if last else defer)(lambda drd=drd, gWr=gWr, ws="slabs2" if last else "slabs": self._tn_acc(
+                    ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"), ws=ws))
                 scr_free[i & 1] = torch.cuda.Event()
                 scr_free[i & 1].record(side)
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
@@ -803,7 +830,11 @@ class MemTransformerLM(nn.Module):
                     hook(G, lo, hi)
         if gE_done is not None:
             main.wait_event(gE_done)          # (gE also received the output-layer weight gradient from the side stream)
-        ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0))
+        if order_ready is not None:
+            main.wait_event(order_ready)
+            for t_ in order_box["o"]:
+                t_.record_stream(main)          # (allocated on the second side stream, read here)
+        ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0), order=order_box["o"])
         join()
         if pad:
             gu_t.view(H, DHt).add_(gu.view(H, DH)[:, :DHt])
@@ -838,23 +869,23 @@ class MemTransformerLM(nn.Module):
             red.append((gW, off, crop))
         ops.reduce_slabs_group(red, slabs, ns, total, True)          # one launch for the whole group
 
-    def _tn_acc(self, dY, Xa, gW, rows=None, crop=None):
+    def _tn_acc(self, dY, Xa, gW, rows=None, crop=None, ws="slabs"):
         """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads.
         crop = (rg, rt, rp, cg, ct, cp): the product has the padded shape [rg*rp, cg*cp]; its [rt, ct] blocks are
-        added to gW [rg*rt, cg*ct]."""
+        added to gW [rg*rt, cg*ct].  ws: name of the slab workspace -- one per stream that may run this concurrently."""
         N = dY.shape[1]
         Kc = Xa.shape[1]
         M = dY.shape[0]
         ns = ops.tn_slices(M, N, Kc)
         fl = self._flat
         need = ns * N * Kc
-        if fl.get("slabs") is None or fl["slabs"].numel() < need:
-            fl["slabs"] = torch.empty(need, device=fl["dev"], dtype=F32)
-        ops.gemm_tn_raw(dY, Xa, fl["slabs"], ns)
+        if fl.get(ws) is None or fl[ws].numel() < need:
+            fl[ws] = torch.empty(need, device=fl["dev"], dtype=F32)
+        ops.gemm_tn_raw(dY, Xa, fl[ws], ns)
         if crop is not None:
             rg, rt, rp, cg, ct, cp = crop
             assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)
-            ops.reduce_slabs_crop(gW, fl["slabs"], crop, ns, N * Kc, True)
+            ops.reduce_slabs_crop(gW, fl[ws], crop, ns, N * Kc, True)
             return
         nrows = N if rows is None else rows
-        ops.reduce_slabs(gW, fl["slabs"], nrows * Kc, ns, N * Kc, True, 1.0)
+        ops.reduce_slabs(gW, fl[ws], nrows * Kc, ns, N * Kc, True, 1.0)

@@ -333,14 +333,27 @@ def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0, ld=None):
     return out
 
 
-def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0):
+def token_order(tok, V):
+    """(perm, offs) for embed_bwd: stable argsort of the ids and the first sorted position of every id (int64 [V+1])."""
+    flat = tok.reshape(-1)
+    vals, perm = torch.sort(flat, stable=True)
+    offs = torch.searchsorted(vals, torch.arange(V + 1, device=tok.device, dtype=vals.dtype))
+    return perm, offs
+
+
+EMBED_SPLITS = 4          # slabs per vocabulary row (bounds the longest list one workgroup walks when a few ids dominate)
+
+
+def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0, order=None):
+    """dE[v] (+)= sqrt(D) * sum over the tokens with id v of the (dropout-masked) dX rows.  order = token_order(tok, V):
+    the sorted kernel (no scan of the token list per row, fixed summation order); None: one workgroup per row scans."""
     V, D = dE.shape
-    nch = call("commu_embed_bwd_chunks", tok.numel(), D, V) if dE.is_contiguous() else 0
-    if nch > 0:          # training-step sizes: per-chunk LDS tables -> slabs -> one reduction into the gradient
-        slabs = torch.empty(nch, V, D, device=dE.device, dtype=F32)
-        call("commu_embed_bwd_slabs", _p(tok), _p(dX), dX.stride(0), _p(slabs), nch, tok.numel(), D, V, int(drop_seed),
-             float(drop_p), _s())
-        reduce_slabs(dE, slabs, V * D, nch, V * D, accumulate, alpha=math.sqrt(D))
+    if order is not None and dE.is_contiguous():
+        perm, offs = order
+        slabs = torch.empty(EMBED_SPLITS, V, D, device=dE.device, dtype=F32)
+        call("commu_embed_bwd_sorted", _p(perm), _p(offs), _p(dX), dX.stride(0), _p(slabs), EMBED_SPLITS, D, V,
+             int(drop_seed), float(drop_p), _s())
+        reduce_slabs(dE, slabs, V * D, EMBED_SPLITS, V * D, accumulate, alpha=math.sqrt(D))
         return dE
     call("commu_embed_bwd", _p(tok), _p(dX), dX.stride(0), _p(dE), tok.numel(), D, V, math.sqrt(D),
          1 if accumulate else 0, int(drop_seed), float(drop_p), _s())

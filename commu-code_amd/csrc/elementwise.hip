@@ -79,42 +79,62 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     }
 }
 
-// The same sums for the training step (65 536 tokens): workgroup (column slice of 32, token chunk) accumulates ITS tokens'
-// rows into an LDS table [V][32] (fp32 LDS atomics: the order of the additions inside a workgroup is not fixed) and writes
-// the table as one slab [chunk][V][D]; commu_reduce_slabs_f32 folds the slabs into the gradient.  Every dX byte is read
-// once; the kernel above reads the token list once per vocabulary row (382 MB at V = 729) and one row at a time.
-constexpr int EMB_VMAX = 768, EMB_SLICE = 32;
-__global__ __launch_bounds__(256) void embed_bwd_slab_kernel(
-    const int64_t* __restrict__ tok, const bf16* __restrict__ dX, int ldx, float* __restrict__ slabs, int ntok, int D,
-    int V, int tok_per_chunk, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
-    __shared__ float tab[EMB_VMAX * EMB_SLICE];
-    const int tid = threadIdx.x, c0 = blockIdx.x * EMB_SLICE, chunk = blockIdx.y;
-    for (int i = tid; i < V * EMB_SLICE; i += 256) tab[i] = 0.f;
-    __syncthreads();
-    const int sub = tid & 3, col = c0 + 8 * sub;          // this thread's 8 columns
-    const int mbeg = chunk * tok_per_chunk, mend = min(ntok, mbeg + tok_per_chunk);
+// The same sums from a token ORDER (stable argsort of the ids + segment offsets per vocabulary row, computed beside the
+// backward pass): workgroup (row v, split s) adds the dX rows of its share of v's tokens -- one row per wave and step,
+// 16 bytes per lane, the next row in flight -- and writes slab [s][v][:]; commu_reduce_slabs_f32 folds the S slabs into
+// the gradient.  No scan of the token list (the kernel above reads it once per vocabulary row: 382 MB at V = 729), no
+// atomics (fp32 LDS atomics cost ~170 cycles per wave instruction here: a table-in-LDS version took 185 us), and the
+// order of the additions is fixed.
+template <int NC>          // NC 8-element chunks per lane: D <= 512 * NC
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(
+    const int64_t* __restrict__ perm, const int64_t* __restrict__ offs, const bf16* __restrict__ dX, int ldx,
+    float* __restrict__ slabs, int D, int V, int S, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
+    __shared__ float red[4][512 * NC];
+    const int v = blockIdx.x, sp = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long b0 = offs[v], b1 = offs[v + 1];
+    const long long per = (b1 - b0 + S - 1) / S, lo = b0 + sp * per, hi = min(b1, lo + per);
     const unsigned key = mix32(drop_seed);
-    if (col < D) {
-        for (int m = mbeg + (tid >> 2); m < mend; m += 64) {
-            const long long v = tok[m];
-            if (v < 0 || v >= V) continue;
-            const bf16x8 x = ld_bf16x8(dX + (size_t)m * ldx + col);          // (row padding beyond D is readable: ldx >= D8)
-            float* t = tab + (int)v * EMB_SLICE + 8 * sub;
+    float acc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 x[NC], nx[NC];
+    long long m = 0, nm = 0;
+    auto fetch = [&](long long k, long long& mm, bf16x8* px) {
+        mm = perm[k];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = lane * 8 + 512 * c;
+            px[c] = col < D ? ld_bf16x8(dX + (size_t)mm * ldx + col) : zero8;          // (row padding beyond D is readable)
+        }
+    };
+    long long k = lo + w;
+    if (k < hi) fetch(k, nm, nx);
+    for (; k < hi; k += 4) {
+        m = nm;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c] = nx[c];
+        if (k + 4 < hi) fetch(k + 4, nm, nx);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = lane * 8 + 512 * c;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                if (col + e >= D) break;
-                float f = bf2f(x[e]);
+                float f = bf2f(x[c][e]);
                 if (drop_thr) f = mix32k((unsigned)m * (unsigned)D + (unsigned)(col + e), key) >= drop_thr ? f * drop_scale : 0.f;
-                atomicAdd(t + e, f);
+                if (col + e < D) acc[c][e] += f;
             }
         }
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[w][lane * 8 + 512 * c + e] = acc[c][e];
     __syncthreads();
-    float* out = slabs + (size_t)chunk * V * D;
-    for (int i = tid; i < V * EMB_SLICE; i += 256) {
-        const int v = i >> 5, c = c0 + (i & 31);
-        if (c < D) out[(size_t)v * D + c] = tab[i];
-    }
+    float* out = slabs + ((size_t)sp * V + v) * D;
+    for (int i = threadIdx.x; i < D; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
 // K2: sinusoid table indexed by DISTANCE d (pos = d): out[d] = [sin(d f) | cos(d f)]
@@ -646,18 +666,16 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
     return 0;
 }
 
-extern "C" int commu_embed_bwd_chunks(int ntok, int D, int V) {
-    if (V > EMB_VMAX || ntok < 4096) return 0;          // (small inputs: the one-workgroup-per-row kernel)
-    int n = (ntok + 4095) / 4096;
-    return n > 16 ? 16 : n;
-}
-
-extern "C" int commu_embed_bwd_slabs(const int64_t* tok, const void* dX, int ldx, float* slabs, int nchunks, int ntok,
-                                     int D, int V, unsigned drop_seed, float drop_p, hipStream_t stream) {
-    if (V > EMB_VMAX || nchunks <= 0 || ldx < ((D + 7) & ~7) || (ldx % 8)) return -22;
-    const int tpc = (((ntok + nchunks - 1) / nchunks) + 63) / 64 * 64;
-    COMMU_LAUNCH(embed_bwd_slab_kernel, dim3((D + EMB_SLICE - 1) / EMB_SLICE, nchunks), dim3(256), 0, stream, tok,
-                 (const bf16*)dX, ldx, slabs, ntok, D, V, tpc, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+extern "C" int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* slabs,
+                                      int nsplit, int D, int V, unsigned drop_seed, float drop_p, hipStream_t stream) {
+    if (V <= 0 || nsplit <= 0 || D > 1024 || ldx < ((D + 7) & ~7) || (ldx % 8)) return -22;
+    const dim3 grid(V, nsplit);
+    if (D <= 512)
+        COMMU_LAUNCH(embed_bwd_sorted_kernel<1>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, slabs, D, V,
+                     nsplit, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+    else
+        COMMU_LAUNCH(embed_bwd_sorted_kernel<2>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, slabs, D, V,
+                     nsplit, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
     COMMU_LAUNCH_CHECK();
     return 0;
 }

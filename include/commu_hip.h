@@ -139,12 +139,12 @@ int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo,
                     float scale, unsigned drop_seed, float drop_p, hipStream_t stream);
 int commu_embed_bwd(const int64_t* tok, const void* dX_bf16, int ldx, float* dE, int ntok, int D, int V,
                     float scale, int accumulate, unsigned drop_seed, float drop_p, hipStream_t stream);
-/* the same through token chunks (training-step sizes): commu_embed_bwd_chunks(ntok, D, V) > 0 gives the number of slabs;
- * commu_embed_bwd_slabs writes slabs[chunk][V][D] = sum over the chunk's tokens of the (dropout-masked) dX rows, unscaled;
- * dE (+)= scale * sum of the slabs is commu_reduce_slabs_f32's.  V <= 768. */
-int commu_embed_bwd_chunks(int ntok, int D, int V);
-int commu_embed_bwd_slabs(const int64_t* tok, const void* dX, int ldx, float* slabs, int nchunks, int ntok, int D, int V,
-                          unsigned drop_seed, float drop_p, hipStream_t stream);
+/* the same from a token order: perm = stable argsort of tok (int64 [ntok]), offs[v] = first position of id v in the sorted
+ * list (int64 [V+1]; ids outside [0, V) fall outside offs[0]..offs[V] and contribute nothing).  Writes
+ * slabs[s][V][D] = unscaled (dropout-masked) row sums of split s of every id's tokens, s < nsplit;
+ * dE (+)= scale * sum of the slabs is commu_reduce_slabs_f32's.  Fixed summation order, no atomics. */
+int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* slabs, int nsplit,
+                           int D, int V, unsigned drop_seed, float drop_p, hipStream_t stream);
 /* sinusoid table by distance d: out[d] = [sin(d f) | cos(d f)]  (PositionalEmbedding, model.py:136-152) */
 int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, unsigned drop_seed,
                      float drop_p, hipStream_t stream);

@@ -39,3 +39,13 @@ t = timeit(lambda: ops.layernorm_bwd_reduce(part, dg, db, dbias))
 print(f"layernorm_bwd_reduce         {t:7.1f} us")
 t = timeit(lambda: ops.colsum(big, ob))
 print(f"colsum [65536,1024] bf16     {t:7.1f} us  {rows * 1024 * 2 / t / 1e6:6.2f} TB/s")
+# embedding backward at the bench size (65 536 tokens, V = 729, D = 512), dropout on
+tok = torch.randint(0, 729, (rows,), device=dev)
+dE = torch.zeros(729, D, device=dev)
+order = ops.token_order(tok, 729)
+t = timeit(lambda: ops.embed_bwd(tok, dy, dE, accumulate=True, drop_p=0.1, drop_seed=5, order=order))
+print(f"embed_bwd (sorted + reduce)  {t:7.1f} us")
+t = timeit(lambda: ops.token_order(tok, 729))
+print(f"token_order (torch)          {t:7.1f} us")
+t = timeit(lambda: ops.embed_bwd(tok, dy, dE, accumulate=True, drop_p=0.1, drop_seed=5))
+print(f"embed_bwd (row scan)         {t:7.1f} us")

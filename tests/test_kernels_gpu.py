@@ -304,9 +304,9 @@ def test_embed_fwd_bwd():
 
 
 @pytest.mark.parametrize("D,ld", [(512, 512), (500, 512), (128, 136)])
-def test_embed_bwd_token_chunks(D, ld):
-    """Training-step sizes take the chunked kernel (LDS tables -> slabs -> reduce): against index_add, with dropout,
-    collisions, ids outside the vocabulary (ignored) and a row stride wider than D."""
+def test_embed_bwd_token_order(D, ld):
+    """The sorted-order kernel (stable argsort of the ids + segment offsets -> slabs -> reduce): against index_add, with
+    dropout, collisions, ids outside the vocabulary (ignored) and a row stride wider than D; bit-identical run to run."""
     o = ops()
     V, n = 729, 9000
     tok = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(13))
@@ -320,10 +320,17 @@ def test_embed_bwd_token_chunks(D, ld):
     ok = ((tok >= 0) & (tok < V))
     ref = torch.zeros(V, D).index_add_(0, tok[ok], (dX[:, :D].float() * keep / (1 - p))[ok]) * math.sqrt(D)
     dE = torch.ones(V, D, device=DEV)
-    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], dE, accumulate=True, drop_p=p, drop_seed=seed)
+    order = o.token_order(tok.to(DEV), V)
+    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], dE, accumulate=True, drop_p=p, drop_seed=seed, order=order)
     assert relerr(dE - 1, ref) < 1e-5
-    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], dE, accumulate=False)
+    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], dE, accumulate=False, order=order)
     assert relerr(dE, torch.zeros(V, D).index_add_(0, tok[ok], dX[:, :D].float()[ok]) * math.sqrt(D)) < 1e-5
+    again = torch.empty_like(dE)
+    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], again, accumulate=False, order=order)
+    assert torch.equal(dE, again)
+    scan = torch.empty_like(dE)          # the scanning kernel (no order) agrees
+    o.embed_bwd(tok.to(DEV), dX.to(DEV)[:, :D], scan, accumulate=False)
+    assert relerr(scan, dE.cpu()) < 1e-5
 
 
 def test_out_of_range_ids_poison_the_loss():
