@@ -18,15 +18,19 @@ class _MaskedMean(torch.autograd.Function):
         t = target.contiguous().view(-1)
         ops.masked_mean(n, t, int(pad_id), float(scale), ws_sum, ws_cnt, out)
         ctx.t, ctx.cnt, ctx.pad, ctx.scale, ctx.shape = t, ws_cnt, int(pad_id), float(scale), nll.shape
-        return out[0]
+        ctx.mark_non_differentiable(ws_sum)
+        return out[0], ws_sum
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gsum):
         g = torch.empty(ctx.t.numel(), device=ctx.t.device, dtype=torch.float32)
         ops.loss_grad(ctx.t, ctx.pad, ctx.cnt, ctx.scale, g)
         return (g * gout).view(ctx.shape), None, None, None
 
 
-def masked_mean(nll, target, pad_id=0, scale=1.0):
-    """scale * mean(nll[target != pad_id])  -- scale = 1 / batch_chunk in the training loop."""
-    return _MaskedMean.apply(nll, target, pad_id, scale)
+def masked_mean(nll, target, pad_id=0, scale=1.0, with_sum=False):
+    """scale * mean(nll[target != pad_id])  -- scale = 1 / batch_chunk in the training loop.
+    with_sum: also the raw sum of nll over the non-pad targets (device tensor [1]): what the reference's logging window
+    accumulates as loss * token count * batch_chunk (train.py:150-154), without the five small kernels of that expression."""
+    loss, nll_sum = _MaskedMean.apply(nll, target, pad_id, scale)
+    return (loss, nll_sum) if with_sum else loss

@@ -91,7 +91,7 @@ class Trainer:
         for i in range(chunk):
             d, t, r = data_chunks[i].contiguous(), target_chunks[i].contiguous(), reset_chunks[i].contiguous()
             loss, self.mems[i] = model(d, t, r, self.mems[i])
-            loss = masked_mean(loss, t, self.pad_id, 1.0 / chunk)
+            loss, nll_sum = masked_mean(loss, t, self.pad_id, 1.0 / chunk, with_sum=True)
             if overlap and i == chunk - 1:
                 # gradients are complete once the LAST micro-batch's backward has passed a layer: exchange that
                 # layer's slice while the layers below are still being differentiated
@@ -104,7 +104,8 @@ class Trainer:
             total = loss.detach() if total is None else total + loss.detach()
             # train.py:150-154: the logging window accumulates the SUM of the micro-batch's token NLLs
             # (mean / chunk * count * chunk), kept on the device -- the reference syncs here with .item()
-            self.log_train_loss += loss.detach() * (t != self.pad_id).sum() * chunk
+            # (= loss * non-pad count * chunk; the masked-mean kernel has that sum already)
+            self.log_train_loss += nll_sum[0]
         if self.reducer is not None:
             if overlap:
                 self.reducer.finish(model._ensure_flat()["g"])
