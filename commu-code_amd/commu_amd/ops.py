@@ -539,7 +539,11 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 # normalisation arithmetic cost a latency-bound skinny GEMM more than the launch they save -- so it is OFF by default.
 FUSE_DECODE_LN = False
 STORE_ATTN_P = True         # backward: bwd_q stores P for bwd_kv (d_head 64); False: both kernels recompute it
-DELTA_KERNEL = False        # tests / A-B runs: delta from commu_attn_delta instead of inside the query-stationary kernel
+# delta = rowsum(o . dO): the separate commu_attn_delta launch (True) or inside the query-stationary kernel
+# (commu_attn_bwd_desc.o).  In the step the two are equal (16.35 / 16.44 vs 16.36 / 16.44 ms): the 30 us launch goes, but
+# every one of bwd_q's 8192 short-lived workgroups pays the extra prologue (0.563 vs 0.525-0.54 ms per launch), so the
+# kernel stays lean and the launch stays
+DELTA_KERNEL = True
 NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead of commu_relattn_bwd_band
 
 

@@ -591,6 +591,35 @@ def test_relattn_fwd(case):
     assert float((lse.cpu() - ref_lse).abs().max()) < 6e-3   # bf16 (q+u), (q+v) operands
 
 
+def test_relattn_bwd_delta_inside_the_query_kernel():
+    """commu_attn_bwd_desc.o: the query-stationary kernel computes delta = rowsum(o . dO) itself and writes it for the
+    key-stationary kernel (ops.DELTA_KERNEL = False) -- same gradients as with the separate commu_attn_delta launch."""
+    o = ops()
+    T, M, B, H, DH = 96, 40, 3, 2, 64
+    K, HD = T + M, H * DH
+    qkv, rd, u, vb = make_attn_inputs(T, M, B, H, DH, 50)
+    g = qkv.to(DEV)
+    q, k, v = g[M * B:, :HD], g[:, HD:2 * HD], g[:, 2 * HD:]
+    dout = bf(rnd(T * B, HD, seed=51)).to(DEV)
+    out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M, save_q=True)
+    res = []
+    keep = o.DELTA_KERNEL
+    try:
+        for flag in (True, False):
+            o.DELTA_KERNEL = flag
+            dqkv = torch.zeros_like(g)
+            drd = torch.zeros(K, HD, device=DEV)
+            du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
+            delta = o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M, out, dout, lse, qs,
+                                  dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
+            torch.cuda.synchronize()
+            res.append((dqkv.float().cpu(), drd.cpu(), du.cpu(), dvb.cpu()))
+    finally:
+        o.DELTA_KERNEL = keep
+    for a_, b_ in zip(res[0], res[1]):
+        assert relerr(b_, a_) < 2e-3
+
+
 @pytest.mark.parametrize("store_p", [False, True], ids=["recompute", "stored_p"])
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_relattn_bwd(case, store_p):
