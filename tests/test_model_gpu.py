@@ -456,3 +456,47 @@ def test_relu_sign_bits_option_gives_identical_gradients(monkeypatch):
     for ga, gb in zip(out[0][1], out[1][1]):          # (bias / LayerNorm-parameter column sums use fp32 atomics: order noise)
         assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12
     assert any(float(g.abs().max()) > 0 for g in out[0][1])
+
+
+@pytest.mark.gpu
+def test_persistent_attention_scratch_under_changing_reset_patterns():
+    """The dS-by-distance / P scratch lives across layers and steps and is never cleared; with reset_mems the kernel
+    zero-writes the distances of the memory tiles a fresh sequence skips.  Ten steps with a different reset pattern each
+    (XL memory carried over) must give the gradients of a run whose scratch is fresh and NaN-poisoned at every call."""
+    from commu_amd import ops
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import build_model
+    dev = torch.device("cuda", 0)
+    T, M, B = 64, 128, 8
+    cfg = get_cfg(num_layers=2, num_heads=2, units=128, inner_size=256, tgt_length=T, mem_length=M, batch_size=B,
+                  batch_chunk=1, dropout=0.0, attention_dropout=0.0)
+    gen = torch.Generator().manual_seed(17)
+    steps = []
+    for i in range(10):
+        d, t, _, _ = synthetic_batch(T, B, dev, seed=100 + i)
+        r = (torch.rand(B, generator=gen) < 0.4).to(dev)
+        if i == 3:
+            r[:] = False
+        if i == 6:
+            r[:] = True
+        steps.append((d, t, r))
+    grads = []
+    for poison in (False, True):
+        model = build_model(cfg, BaseVocab(), dev, seed=9)
+        model.train()
+        mems, run = None, []
+        ops.POISON_SCRATCH = poison
+        try:
+            for d, t, r in steps:
+                model.zero_grad()
+                loss, mems = model(d, t, r, mems)
+                loss.float().mean().backward()
+                run.append([p.grad.detach().clone() for p in model.parameters()])
+        finally:
+            ops.POISON_SCRATCH = False
+        grads.append(run)
+    for sa, sb in zip(*grads):
+        for ga, gb in zip(sa, sb):
+            assert torch.isfinite(ga).all() and torch.isfinite(gb).all()
+            assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-10
