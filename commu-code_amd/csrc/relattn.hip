@@ -796,6 +796,33 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     // exponent (lse2 below), delta is pre-multiplied per row -- per element: exp2, select, subtract, multiply
     const float dsc = DROP ? a.drop_scale : 1.f;
 
+    // every global load of the prologue is requested before anything waits (a workgroup lives ~30 us and its prologue is
+    // exposed): the first K / V / band tile and the band's upper chunk(s) here, then the query-side fragments and the
+    // row statistics; the LDS ring is cleared and the statistics are folded while they are in flight
+    int jt_lo, jt_hi;
+    kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
+    const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
+    const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
+    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
+    Stager<64, DH, NTHR> stK, stV, stR, stU[NCH - 1];
+    stK.init(rsb, tid);
+    stV.init(rsb, tid);
+    stR.init((unsigned)a.ld_rd * 2u, tid);
+    const unsigned rdb = (unsigned)a.ld_rd * 2u;
+    auto issue = [&](int jt) {
+        const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
+        stK.load(srdK, (unsigned)j0 * rsb);
+        stV.load(srdV, (unsigned)j0 * rsb);
+        stR.load(srdR, (unsigned)dlo * rdb);
+    };
+    issue(jt_lo);
+#pragma unroll
+    for (int kc = 1; kc < NCH; ++kc) {      // upper chunks of the first band
+        stU[kc - 1].init((unsigned)a.ld_rd * 2u, tid);
+        stU[kc - 1].load(srdR, (unsigned)(i0 + M - jt_lo * 64 - 63 + 64 * kc) * rdb);
+    }
+
     bf16x8 qu[KS], qv[KS], dof[KS];
     float drow = 0.f;          // a.o_in: delta of row r16 (sum over d of o . dout), in every lane of that row after the reduction
     {
@@ -847,34 +874,11 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
 #pragma unroll
     for (int d = 0; d < DB; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int jt_lo, jt_hi;
-    kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
     bf16* myD = sD + w * 64 * PT;
     for (int n = lane; n < 16 * SPITCH / 8; n += 64) *(bf16x8*)(myS + n * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-
-    const size_t kvbytes = ((size_t)(K - 1) * B * a.ld_qkv + DH) * 2;
-    const srd_t srdK = make_srd(a.k + (size_t)b * a.ld_qkv + h * DH, kvbytes);
-    const srd_t srdV = make_srd(a.v + (size_t)b * a.ld_qkv + h * DH, kvbytes);
-    const srd_t srdR = make_srd(a.rd + h * DH, ((size_t)(K - 1) * a.ld_rd + DH) * 2);
-    Stager<64, DH, NTHR> stK, stV, stR;
-    stK.init(rsb, tid);
-    stV.init(rsb, tid);
-    stR.init((unsigned)a.ld_rd * 2u, tid);
-    const unsigned rdb = (unsigned)a.ld_rd * 2u;
-    auto issue = [&](int jt) {
-        const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
-        stK.load(srdK, (unsigned)j0 * rsb);
-        stV.load(srdV, (unsigned)j0 * rsb);
-        stR.load(srdR, (unsigned)dlo * rdb);
-    };
     {
 #pragma unroll
-        for (int kc = 1; kc < NCH; ++kc) {      // upper chunks of the first band (chunk kc sits in slot kc at t = 0)
-            const int dk = i0 + M - jt_lo * 64 - 63 + 64 * kc;
-            stR.load(srdR, (unsigned)dk * rdb);
-            stR.store(sR + kc * 64 * DH);
-        }
-        issue(jt_lo);
+        for (int kc = 1; kc < NCH; ++kc) stU[kc - 1].store(sR + kc * 64 * DH);      // (chunk kc sits in slot kc at t = 0)
         stK.store(sK);
         stV.store(sV);
         stR.store(sR);
