@@ -1026,16 +1026,30 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
             }
         }
     }
+    // dq (AC part) leaves through the wave's dS^T scratch as whole 16-byte pieces (sixteen 2-byte stores per lane before)
+    static_assert(64 * PT >= 16 * DH, "the per-wave scratch holds a 16 x DH tile");
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 4 * g + reg, col = 16 * d + r16;
+            myD[row * DH + ((((col >> 3) ^ (row & 7)) & (DH / 8 - 1)) << 3) + (col & 7)] = f2bf(dq[d][reg]);
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < DH / 32; ++n) {          // 16 rows x DH / 8 pieces over 64 lanes
+        const int idx = lane + 64 * n, row = idx / (DH / 8), ch = idx % (DH / 8), i = iw_lo + row;
+        if (i < T)
+            st_bf16x8(a.dq + ((size_t)i * B + b) * HD + h * DH + 8 * ch,
+                      ld_bf16x8(myD + row * DH + (((ch ^ (row & 7)) & (DH / 8 - 1)) << 3)));
+    }
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
         float ca = 0.f;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int i = i0 + 16 * w + 4 * g + reg;
-            if (i < T) {
-                a.dq[((size_t)i * B + b) * HD + h * DH + 16 * d + r16] = f2bf(dq[d][reg]);
-                ca += dq[d][reg];
-            }
+            if (i < T) ca += dq[d][reg];
         }
         ca += __shfl_xor(ca, 16, 64);
         ca += __shfl_xor(ca, 32, 64);
