@@ -484,6 +484,66 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     }
 }
 
+// The same for rows of at most 768 logits with a 16-byte aligned stride (the model's: 729 of 768): the row is read ONCE,
+// 16 bytes per lane and load, and kept in registers for both passes.
+__global__ __launch_bounds__(256) void ce_fwd_vec_kernel(const float* __restrict__ logits, int ldl,
+                                                         const int64_t* __restrict__ target, float* __restrict__ nll,
+                                                         float* __restrict__ lse, int rows, int V) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = logits + (size_t)row * ldl;
+    f32x4 x[3];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = 4 * lane + 256 * k;
+        x[k] = c < ldl ? *(const f32x4*)(p + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e >= V) x[k][e] = -3.0e38f;
+            mx = fmaxf(mx, x[k][e]);
+        }
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += (4 * lane + 256 * k + e < V) ? expf(x[k][e] - mx) : 0.f;
+    s = wave_sum(s);
+    const float l = mx + logf(s);
+    if (lane == 0) {
+        lse[row] = l;
+        const long long tg = target[row];          // (outside [0, V): NaN, the reference's gather would raise)
+        nll[row] = (tg >= 0 && tg < V) ? l - p[tg] : __builtin_nanf("");
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_vec_kernel(const float* __restrict__ logits, int ldl,
+                                                         const int64_t* __restrict__ target,
+                                                         const float* __restrict__ lse, const float* __restrict__ g,
+                                                         bf16* __restrict__ dlogits, int ldd, int rows, int V) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = logits + (size_t)row * ldl;
+    bf16* o = dlogits + (size_t)row * ldd;
+    const float l = lse[row], gr = g[row];
+    const int t = (int)target[row];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int c = 4 * lane + 256 * k;
+        if (c >= ldd) break;
+        const f32x4 x = c < ldl ? *(const f32x4*)(p + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = f2bf(c + e < V ? gr * (expf(x[e] - l) - (c + e == t ? 1.f : 0.f)) : 0.f);
+        *(bf16x4*)(o + c) = v;
+    }
+}
+
 // dlogits[m, n] = g[m] * (softmax(logits[m])[n] - [n == target[m]]), bf16, zero in pad columns
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ldl,
                                                      const int64_t* __restrict__ target,
@@ -775,7 +835,10 @@ extern "C" int commu_colsum_f32(const float* X, int ldx, int rows, int cols, flo
 extern "C" int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse,
                             int rows, int V, hipStream_t stream) {
     if (rows <= 0) return 0;
-    COMMU_LAUNCH(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, nll,
+    if (V <= 768 && ldl <= 768 && (ldl % 4) == 0 && (((size_t)logits) & 15) == 0)
+        COMMU_LAUNCH(ce_fwd_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, nll, lse, rows, V);
+    else
+        COMMU_LAUNCH(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, nll,
                        lse, rows, V);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -784,7 +847,12 @@ extern "C" int commu_ce_fwd(const float* logits, int ldl, const int64_t* target,
 extern "C" int commu_ce_bwd(const float* logits, int ldl, const int64_t* target, const float* lse,
                             const float* g, void* dlogits, int ldd, int rows, int V, hipStream_t stream) {
     if (rows <= 0) return 0;
-    COMMU_LAUNCH(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, lse,
+    if (V <= 768 && ldl <= 768 && ldd <= 768 && (ldl % 4) == 0 && (ldd % 4) == 0 && ldd <= ldl + 3 && (((size_t)logits) & 15) == 0 &&
+        (((size_t)dlogits) & 7) == 0)
+        COMMU_LAUNCH(ce_bwd_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, lse, g,
+                     (bf16*)dlogits, ldd, rows, V);
+    else
+        COMMU_LAUNCH(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, logits, ldl, target, lse,
                        g, (bf16*)dlogits, ldd, rows, V);
     COMMU_LAUNCH_CHECK();
     return 0;
