@@ -572,7 +572,15 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
                                                             float* __restrict__ part) {
     __shared__ float red[4];
     float s = 0.f;
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    const size_t step = (size_t)gridDim.x * 1024;
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (; i + 3 * step + 3 < n; i += 4 * step) {          // four independent 16-byte loads in flight per lane
+        const f32x4 v0 = *(const f32x4*)(g + i), v1 = *(const f32x4*)(g + i + step), v2 = *(const f32x4*)(g + i + 2 * step),
+                    v3 = *(const f32x4*)(g + i + 3 * step);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v0[e] * v0[e] + v1[e] * v1[e] + v2[e] * v2[e] + v3[e] * v3[e];
+    }
+    for (; i < n; i += step) {
         if (i + 3 < n) {
             f32x4 v = *(const f32x4*)(g + i);
             s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
