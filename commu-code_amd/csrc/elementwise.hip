@@ -22,6 +22,23 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
     const float* src = E + (size_t)(bad ? 0 : id) * D;
     bf16* dst = out + (size_t)m * ldo;
     const int Dz = min(ldo, (D + 63) & ~63);          // zero-padding contract: columns [D, Dz) are written as 0
+    if ((D & 7) == 0 && (ldo & 7) == 0) {          // 8 columns per lane: two 16-byte loads, one 16-byte store
+        const unsigned key = mix32(drop_seed);
+        for (int c = lane * 8; c < Dz; c += 512) {
+            bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c < D) {
+                const f32x4 v0 = *(const f32x4*)(src + c), v1 = *(const f32x4*)(src + c + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = bad ? __builtin_nanf("") : (e < 4 ? v0[e & 3] : v1[e & 3]) * scale;
+                    if (drop_thr) x = mix32k((unsigned)m * (unsigned)D + (unsigned)(c + e), key) >= drop_thr ? x * drop_scale : 0.f;
+                    o[e] = f2bf(x);
+                }
+            }
+            st_bf16x8(dst + c, o);
+        }
+        return;
+    }
     for (int c = lane * 4; c < Dz; c += 256) {
         if (c >= D) { *(bf16x4*)(dst + c) = (bf16x4){0, 0, 0, 0}; continue; }
         f32x4 v = *(const f32x4*)(src + c);
