@@ -957,8 +957,14 @@ static bool tn_group_plan(const commu_tn_problem* probs, int nprob, int M, Tn8Ar
 extern "C" int commu_gemm_tn_grouped_slices(const commu_tn_problem* probs, int nprob, int M) {
     Tn8Args a;
     if (!tn_group_plan(probs, nprob, M, &a)) return 0;
-    // one workgroup per CU: tiles x slices <= 256, slices a multiple of 8 when possible (one slice per XCD)
-    int s = 256 / a.total_tiles;
+    // tiles x slices <= 128 workgroups: HALF the CUs.  A workgroup of this kernel owns its CU's register file for its
+    // whole life, and the launch runs on the side stream beside the backward pass: with 256 workgroups every main-stream
+    // kernel issued meanwhile waits for CUs; with 128 (16 per XCD) half of every XCD stays free, the launch takes
+    // twice as long and still ends well inside its layer (measured per step: 256 -> 16.55 ms, 128 -> 16.18, 192 -> 16.24,
+    // 64 -> 16.63, 512 -> 16.73; reference default config 34.1 -> 32.6 ms).  Half as many slabs to reduce as well.
+    int budget = 128;
+    if (const char* e = getenv("COMMU_TN8_WGS")) budget = atoi(e);
+    int s = budget / a.total_tiles;
     if (s >= 8) s &= ~7;
     if (s < 1) s = 1;
     const int cap = (M + 1023) / 1024;          // at least 16 K-tiles per workgroup
