@@ -156,12 +156,21 @@ class _Prefetcher:
                 if slot["event"] is not None:
                     slot["event"].synchronize()                   # the copy out of this slot has finished
                 extra = produce(slot["bufs"])
-                if extra is None:                                 # end of the stream
-                    self.ready.put(None)
-                    return
-                self.ready.put((i, extra))
+                if not self._put(None if extra is None else (i, extra)) or extra is None:
+                    return                                        # closed, or end of the stream
         except BaseException as exc:                              # surfaced in the consumer
-            self.ready.put(exc)
+            self._put(exc)
+
+    def _put(self, item):
+        """ready.put that gives up when the iterator was closed (a worker blocked on a full queue would otherwise
+        never wake: an abandoned iterator leaked its thread and its pinned buffers)."""
+        while not self.stop:
+            try:
+                self.ready.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def __iter__(self):
         return self
@@ -186,6 +195,13 @@ class _Prefetcher:
     def close(self):
         self.stop = True
         self.idle.put(None)
+        try:                                                      # unblock a worker waiting on a full queue
+            while True:
+                self.ready.get_nowait()
+        except queue.Empty:
+            pass
+        if self.thread is not threading.current_thread():
+            self.thread.join(timeout=2.0)
 
 
 class ComMUDataset:

@@ -867,7 +867,22 @@ class MemTransformerLM(nn.Module):
             else:
                 crop = (1, N if rows is None else rows, N, 1, Kc, Kc)
             red.append((gW, off, crop))
-        ops.reduce_slabs_group(red, slabs, ns, total, True)          # one launch for the whole group
+        # One reduce launch for the whole group -- EXCEPT that items whose destinations overlap must not share a launch:
+        # with mem_len == tgt_len the memory-side k|v gradient (dst = gW[HDt:]) has the token count of the qkv gradient
+        # (dst = gW) and lands in this group; two workgroup sets would read-modify-write the same rows with no ordering.
+        # Overlapping items go to consecutive launches (stream order = accumulation order).
+        batches = []
+        for item in red:
+            lo = item[0].data_ptr()
+            hi = lo + item[0].numel() * item[0].element_size()
+            for bt in batches:
+                if all(hi <= l2 or h2 <= lo for l2, h2, _ in bt):
+                    bt.append((lo, hi, item))
+                    break
+            else:
+                batches.append([(lo, hi, item)])
+        for bt in batches:
+            ops.reduce_slabs_group([it for _, _, it in bt], slabs, ns, total, True)
 
     def _tn_acc(self, dY, Xa, gW, rows=None, crop=None, ws="slabs"):
         """gW[:rows] += dY^T @ Xa (weight gradient).  gW is a contiguous fp32 view of the flat grads.

@@ -165,7 +165,8 @@ def gemm_nt(A, B, out=None, *, bias=None, resid=None, relu=False, relu_mask=None
         assert bits.dtype == torch.int32 and bits.is_contiguous() and bits.numel() * 32 == M * N
         flags |= EPI_SIGNBITS_OUT if sign_bits_out is not None else EPI_RELUBITS
         relu_mask = bits          # (the C entry point takes the word buffer in the relu_mask argument)
-        call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid), 0, _p(bits), 0,
+        call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid),
+             0 if resid is None else _rowmajor2d(resid, "resid"), _p(bits), 0,
              flags, int(drop_seed), float(drop_p), float(mask_scale), _s())
         return out
     call("commu_gemm_nt_bf16", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid),
@@ -615,9 +616,6 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
             if POISON_SCRATCH:
                 pscr.fill_(float("nan"))
         e.p_scratch = pscr.data_ptr()
-    import os as _os
-    if _os.environ.get("COMMU_ABL_DSK"):          # profiling ablation: bwd_q without its dS-by-distance stores
-        e.dsk_wedge = -7
     assert dv.stride(0) == dk.stride(0)
     if not (DELTA_KERNEL or o.stride(0) != dout.stride(0)):
         e.o = o.data_ptr()

@@ -220,3 +220,42 @@ def test_training_learns_a_deterministic_rule():
         last = float(loss.detach())
         first = last if first is None else first
     assert first > 6.0 and last < 0.1, (first, last)
+
+
+@pytest.mark.parametrize("mem_len,T,B", [(0, 256, 16), (256, 256, 16), (128, 256, 16)],
+                         ids=["nomem", "mem_eq_tgt", "mem_lt_tgt"])
+def test_grouped_weight_gradients_match_the_per_gemm_path(mem_len, T, B, monkeypatch):
+    """The production weight-gradient path (grouped eight-phase TN launch + ONE grouped slab reduction, side streams)
+    against the per-GEMM fallback (`COMMU_TN8_OFF`) at T*B >= 4096, where the grouped kernel is eligible -- including
+    mem_len == tgt_len, where the memory-side k|v gradient has the token count of the qkv gradient and both add into
+    the same rows of qkv_net.weight.grad (they must not share one reduce launch).  Same seeds, dropout off: every
+    gradient tensor agrees to fp32-reduction-order noise, on repeated runs (the old race was nondeterministic)."""
+    L, H, D, DI = 2, 4, 256, 512
+    model, cfg, s, params = build(L, H, D, DI, T, mem_len, seed=17)
+    model.eval()
+    g = torch.Generator().manual_seed(23)
+    segs = [(torch.randint(1, 729, (T, B), generator=g), torch.randint(1, 729, (T, B), generator=g)) for _ in range(2)]
+
+    def grads():
+        model.zero_grad()
+        mems = None
+        for data, target in segs:
+            loss, mems = model(data.to(DEV), target.to(DEV), torch.zeros(B, dtype=torch.bool, device=DEV), mems)
+            loss.float().mean().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv("COMMU_TN8_OFF", "1")
+    ref = grads()
+    monkeypatch.delenv("COMMU_TN8_OFF")
+    from commu_amd import ops
+    dY = torch.zeros(T * B, 3 * D, device=DEV, dtype=torch.bfloat16)
+    Xa = torch.zeros(T * B, D, device=DEV, dtype=torch.bfloat16)
+    arr, Mtok, _, _ = ops.tn_group([(dY, Xa)])
+    assert ops.tn_group_slices(arr, Mtok) > 0, "the grouped kernel must be eligible at this shape"
+    for rep in range(3):
+        got = grads()
+        for n in ref:
+            scale = float(ref[n].abs().max()) + 1e-12
+            err = float((got[n] - ref[n]).abs().max()) / scale
+            assert err < 2e-3, (mem_len, rep, n, err)

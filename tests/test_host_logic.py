@@ -256,3 +256,24 @@ def test_reference_written_checkpoint_is_readable_without_the_reference(golden_d
     assert isinstance(ck["vocab"], BaseVocab) and len(ck["vocab"]) == 729 and ck["amp"] is None
     assert ck["train_step"] == 3 and "layers.1.dec_attn.r_net.weight" in ck["model"]
     assert set(ck["optimizer"]["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_abandoned_iterator_releases_its_prefetch_thread():
+    """A train iterator dropped after one batch (eval iterators are recreated every eval interval; generators are
+    dropped early): the prefetch worker -- possibly blocked on its full ready queue -- must terminate."""
+    import threading
+    rng = np.random.default_rng(3)
+    seqs = [rng.integers(2, 700, size=int(n)).astype(np.int64) for n in rng.integers(40, 90, size=24)]
+    cfg = get_cfg(tgt_length=16, mem_length=0, batch_size=4)
+    ds = ComMUDataset(None, cfg, sequences={"train": seqs, "valid": seqs[:6]})
+    before = threading.active_count()
+    for _ in range(3):
+        it = ds.get_iterator(4, 16, "cpu", "train", True, seed=1)()
+        next(it)
+        import time
+        time.sleep(0.05)                                          # let the worker fill its queue and block
+        it.close()
+    deadline = time.time() + 5.0
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before
