@@ -332,6 +332,9 @@ def main():
     ap.add_argument("--tgt-len", dest="tgt_len", type=int, default=1024)
     ap.add_argument("--mem-len", dest="mem_len", type=int, default=0)
     ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: this many sequences over all ranks (the reference's semantics, train.py:396-397: "
+                         "batch_size // num_gpus columns per rank); default 0 = weak scaling with --batch-per-gpu each")
     ap.add_argument("--batch-chunk", type=int, default=1)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -354,6 +357,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
 
+    scaling = "weak"
+    if args.global_batch > 0:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks (train.py:396)")
+        args.batch_per_gpu, scaling = args.global_batch // world, "strong"
     B = args.batch_per_gpu
     elapsed, tokens_per_step, prof, pscale = train_bench(args, dev, world, rank, args.steps, args.warmup)
     if rank != 0:
@@ -369,7 +377,7 @@ def main():
     out = {
         "metric": "training tokens/sec at d_model=512 tgt_len=1024",
         "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"transformer-xl train step L{L} D{D} H{H} DI{DI} tgt_len{T} mem_len{M} vocab729",
                    "global_batch": B * world, "batch_per_gpu": B, "batch_chunk": args.batch_chunk, "seq_len": T,

@@ -32,16 +32,20 @@ def make_buckets(total: int, boundaries: List[int], target_elems: int) -> List[T
 class GradReducer:
     """Mean all-reduce of a flat gradient buffer in buckets."""
 
-    def __init__(self, group=None, bucket_mb: float = 16.0):
+    def __init__(self, group=None, bucket_mb: float = 16.0, exchange_single: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._stream = None
         # RCCL reduces to the mean directly; gloo (CPU tests, or CUDA tensors staged through the host) has no AVG
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # exchange_single: run the whole exchange protocol (buckets, communication stream, collectives) in a group of
+        # ONE rank too -- the mean over one rank is the identity, so this only exists to execute the RCCL path on a
+        # single device (tests/test_ddp_gpu.py); a one-rank job otherwise skips the exchange.
+        self._active = self.world > 1 or (exchange_single and dist.is_initialized())
 
     def reduce_flat(self, flat_g: torch.Tensor, boundaries: Optional[List[int]] = None):
-        if self.world == 1:
+        if not self._active:
             return
         buckets = make_buckets(flat_g.numel(), boundaries or [], self.bucket_elems)
         avg = self._avg
@@ -60,29 +64,32 @@ class GradReducer:
         self._handles, self._fired, self._pending, self._events = [], [], None, []
 
     def _fire(self, flat_g, a, b):
+        """Launch the all-reduce of flat_g[a:b], ordered after the pending producer events.  Device tensors: the
+        collective is launched from a dedicated COMMUNICATION STREAM that waits for those events -- whatever the
+        backend: RCCL orders a collective after the stream it is launched from, and gloo's device-tensor path
+        synchronises with that stream before staging through the host -- so neither the main stream nor the
+        weight-gradient streams are ever held up by the exchange."""
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         events, self._events = self._events, []
-        if events and flat_g.is_cuda:
-            if self._avg:
-                # RCCL orders a collective after the stream it is launched from: launch from a stream that waits for the
-                # producers' events, so that neither the main nor the weight-gradient stream is held up
-                if self._stream is None:
-                    self._stream = torch.cuda.Stream(device=flat_g.device)
-                with torch.cuda.stream(self._stream):
-                    for ev in events:
-                        self._stream.wait_event(ev)
-                    self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
-                self._fired.append((a, b))
-                return
-            for ev in events:               # gloo stages device tensors through the host: the data must be there
-                ev.synchronize()
-        self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+        if flat_g.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat_g.device)
+            if not events:                       # no producer events given: everything enqueued on the caller's stream so far
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(flat_g.device))
+                events = [ev]
+            with torch.cuda.stream(self._stream):
+                for ev in events:
+                    self._stream.wait_event(ev)
+                self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+        else:
+            self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
         self._fired.append((a, b))
 
     def range_ready(self, flat_g, lo, hi, events=None):
         """model.grad_ready_hook: flat_g[lo:hi] is final once `events` (one per producing stream; None: now) have
         completed.  Ranges arrive top layer first (descending)."""
-        if self.world == 1:
+        if not self._active:
             return
         if self._pending is not None and self._pending[0] == hi:
             self._pending = (lo, self._pending[1])
@@ -98,7 +105,7 @@ class GradReducer:
     range_ready.wants_events = True
 
     def finish(self, flat_g):
-        if self.world == 1:
+        if not self._active:
             return
         if self._pending is not None:
             self._fire(flat_g, *self._pending)
@@ -109,7 +116,9 @@ class GradReducer:
                 self._fire(flat_g, pos, a)
             pos = max(pos, b)
         for h in self._handles:
-            h.wait()
+            h.wait()                             # (device tensors: the CURRENT stream waits for the collective)
+        if flat_g.is_cuda and self._stream is not None:
+            torch.cuda.current_stream(flat_g.device).wait_stream(self._stream)
         if not self._avg:
             flat_g.mul_(1.0 / self.world)
         self._handles = []

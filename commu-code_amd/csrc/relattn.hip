@@ -486,8 +486,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <bool DROP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void relattn_fwd2_kernel(const AttnArgs a) {
+// STAG: the two halves of the workgroup (waves 0-3 / 4-7: query rows 0-63 / 64-127) run HALF A TILE apart, separated by
+// two barriers per key tile: while one half is in the matrix-heavy first half of a tile (band product, skew, QK^T) the
+// other is in the VALU-heavy second half (softmax, P image, P.V) of the previous one -- on every SIMD one wave of each.
+// K and the band chunk of tile t+1 are requested after the even barrier, V after the odd one (V of tile t-1 is still
+// being read by the late half until then), each waited for with a counted vmcnt two barriers later.
+template <bool DROP, bool STAG, int WPE = 4>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void relattn_fwd2_kernel(const AttnArgs a) {
     constexpr int DH = 64, NW = 8, QROWS = 128, TILE = 64 * DH, KS = 2, DB = 4;
     __shared__ __attribute__((aligned(1024))) bf16 smem[8 * TILE + NW * 64 * PT];          // 64 + 16 KB
     bf16* const sK = smem;                     // [2][64 keys][64]
@@ -560,12 +565,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int jt_lo, jt_hi;
     kv_range(a, i0, QROWS, rst, jt_lo, jt_hi);
     if (rep == 1) __syncthreads();                        // the first tile's buffers are free
-    auto stage = [&](int jt, int tt, int chunk) {          // K, V tile jt and band chunk `chunk` of that tile
+    auto stage_kr = [&](int jt, int tt, int chunk) {          // K tile jt and band chunk `chunk` of that tile
         const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
         const unsigned kvoff = (unsigned)(j0 + drow) * rsb + dchunk;
         lds_dma16(srdK, kvoff, ldsK + (unsigned)(tt & 1) * (TILE * 2u));
-        lds_dma16(srdV, kvoff, ldsV + (unsigned)(tt & 1) * (TILE * 2u));
         lds_dma16(srdR, (unsigned)(dlo + 64 * chunk + drow) * rdb + dchunk, ldsR + (unsigned)((chunk - tt) & 3) * (TILE * 2u));
+    };
+    auto stage_v = [&](int jt, int tt) {
+        lds_dma16(srdV, (unsigned)(jt * 64 + drow) * rsb + dchunk, ldsV + (unsigned)(tt & 1) * (TILE * 2u));
+    };
+    auto stage = [&](int jt, int tt, int chunk) {
+        stage_kr(jt, tt, chunk);
+        stage_v(jt, tt);
     };
     {   // prologue: upper band chunks of the first tile, then the tile itself
         const int dlo = i0 + M - jt_lo * 64 - 63;
@@ -602,14 +613,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float mrow[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     f32x2 lp01 = {0.f, 0.f}, lp23 = {0.f, 0.f};
 
-    for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
+    f32x4 s[4];
+    // a wave whose 16 rows see nothing of a key tile only takes part in the staging
+    auto sees = [&](int jt) {
         const int j0 = jt * 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t has landed
-        __builtin_amdgcn_s_barrier();                            // ... everybody's has; tile t-1 is no longer read
-        if (jt < jt_hi) stage(jt + 1, t + 1, 0);
-        // a wave whose 16 rows see nothing of this key tile only takes part in the staging
-        if (j0 > iw_hi + M || (a.same_length && j0 + 63 <= iw_lo - a.sshift) || iw_lo >= T) continue;
-        const int kb = (t & 1) * (TILE * 2), vb = 2 * TILE * 2 + kb;          // byte bases of this tile's K and V buffers
+        return !(j0 > iw_hi + M || (a.same_length && j0 + 63 <= iw_lo - a.sshift) || iw_lo >= T);
+    };
+    // first half of a tile: band product, skew, QK^T, masks -> s
+    auto half1 = [&](int jt, int t) {
+        const int j0 = jt * 64;
+        const int kb = (t & 1) * (TILE * 2);          // byte base of this tile's K buffer
 
         // band product, one 16-distance block at a time from the top: block pair (4-c, 3-c) gives the skewed diagonal of
         // score block c, BD[row][jj] = QR[row][row - jj + 63] -- the INITIAL value of its accumulator -- so only two band
@@ -628,7 +641,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int reg = 0; reg < 4; ++reg) r[reg] = bperm(srcaddr[reg], lower[reg] ? hi[reg] : lo[reg]);
             return r;
         };
-        f32x4 s[4];
         {
             f32x4 qa = band(4), qb = band(3);
             s[0] = skew(qa, qb);
@@ -655,6 +667,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst)) s[c][reg] = -INFINITY;
             }
         }
+    };
+    // second half: online softmax, P image, P.V
+    auto half2 = [&](int jt, int t) {
+        const int j0 = jt * 64;
+        const int vb = 2 * TILE * 2 + (t & 1) * (TILE * 2);          // byte base of this tile's V buffer
         // online softmax (log2 domain); rescale only when some row's running max moved
         float mx[4];
 #pragma unroll
@@ -725,6 +742,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         __builtin_amdgcn_wave_barrier();                         // P image is rewritten by the next tile
+    };
+    if (!STAG) {
+        for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t has landed
+            __builtin_amdgcn_s_barrier();                            // ... everybody's has; tile t-1 is no longer read
+            if (jt < jt_hi) stage(jt + 1, t + 1, 0);
+            if (!sees(jt)) continue;
+            half1(jt, t);
+            half2(jt, t);
+        }
+    } else {
+        // barrier 2t: K / band of tile t (and, for t = 0, V) have landed; barrier 2t+1: V of tile t has landed.
+        // early half (waves 0-3): half1(t) after barrier 2t, half2(t) after 2t+1; late half: half1(t) after 2t+1,
+        // half2(t) after 2t+2.  NT tiles -> barriers 0 .. 2 NT.
+        const int NT = jt_hi - jt_lo + 1;
+        const int late = w >= 4 ? 1 : 0;
+        for (int n = 0; n <= 2 * NT; ++n) {
+            const int te = n >> 1;                                   // tile whose barrier pair this is
+            if (!(n & 1)) {
+                // even barrier: outstanding = [K, R of tile te] (+ V of tile te, requested after them, when te >= 1)
+                if (te >= 1 && te < NT) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (te + 1 < NT) stage_kr(jt_lo + te + 1, te + 1, 0);      // K buffer / band slot of tile te-1: last read before this barrier
+            } else {
+                // odd barrier: V of tile te must have landed; K, R of tile te+1 (2 requests) may still be in flight
+                if (te + 1 < NT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (te + 1 < NT) stage_v(jt_lo + te + 1, te + 1);          // V buffer of tile te-1: the late half finished it before this barrier
+            }
+            const int m = n - late;
+            if (m < 0 || m >= 2 * NT) continue;
+            const int t = m >> 1;
+            if (!sees(jt_lo + t)) continue;
+            if (m & 1) half2(jt_lo + t, t);
+            else half1(jt_lo + t, t);
+        }
     }
     // epilogue: normalise, O through the wave's P buffer ([16 rows][64] bf16, 16-byte chunk c of row r at chunk
     // c ^ (r & 7)), out as whole 128-byte rows; lse
@@ -1518,8 +1573,17 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     static const int fwd_gen = getenv("COMMU_ATTN_FWD_GEN") ? atoi(getenv("COMMU_ATTN_FWD_GEN")) : 2;
     if (d->DH == 64 && fwd_gen == 2) {          // second-generation kernel: 128 query rows per workgroup
         dim3 grid2((((d->T + 127) / 128 + 1) / 2) * d->H * d->B);
-        if (drop) COMMU_LAUNCH((relattn_fwd2_kernel<true>), grid2, dim3(512), 0, stream, a);
-        else COMMU_LAUNCH((relattn_fwd2_kernel<false>), grid2, dim3(512), 0, stream, a);
+        static const int stag = getenv("COMMU_ATTN_FWD_STAG") ? atoi(getenv("COMMU_ATTN_FWD_STAG")) : 0;
+        if (stag == 1) {
+            if (drop) COMMU_LAUNCH((relattn_fwd2_kernel<true, true, 2>), grid2, dim3(512), 0, stream, a);
+            else COMMU_LAUNCH((relattn_fwd2_kernel<false, true, 2>), grid2, dim3(512), 0, stream, a);
+        } else if (stag == 2) {          // lockstep at the staggered variant's occupancy (two waves per SIMD)
+            if (drop) COMMU_LAUNCH((relattn_fwd2_kernel<true, false, 2>), grid2, dim3(512), 0, stream, a);
+            else COMMU_LAUNCH((relattn_fwd2_kernel<false, false, 2>), grid2, dim3(512), 0, stream, a);
+        } else {
+            if (drop) COMMU_LAUNCH((relattn_fwd2_kernel<true, false>), grid2, dim3(512), 0, stream, a);
+            else COMMU_LAUNCH((relattn_fwd2_kernel<false, false>), grid2, dim3(512), 0, stream, a);
+        }
         COMMU_LAUNCH_CHECK();
         return 0;
     }

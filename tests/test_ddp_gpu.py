@@ -114,3 +114,131 @@ def test_two_rank_training_matches_single_process_with_joint_batch(variant):
     for n, p in model.named_parameters():
         a, b = p.detach().cpu(), p0[n]
         assert torch.allclose(a, b, rtol=0, atol=3e-4), (n, float((a - b).abs().max()))
+
+
+def _cfg_mid(batch):
+    """Large enough that the grouped weight-gradient launches run on the side stream (T*B >= 4096) and lag the main
+    stream: an exchange that starts before its producers have finished would read incomplete gradients."""
+    from commu_amd.model.config_helper import get_cfg
+    return get_cfg(num_layers=4, num_heads=4, units=256, inner_size=512, tgt_length=256, mem_length=0, batch_size=batch,
+                   batch_chunk=1, dropout=0.0, attention_dropout=0.0)
+
+
+def _rccl_single_worker(rank, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from commu_amd.ddp import GradReducer
+        from commu_amd.model.dataset import BaseVocab, synthetic_batch
+        from commu_amd.train import Trainer, build_model
+        cfg = _cfg_mid(16)
+        batches = [synthetic_batch(256, 16, dev, seed=900 + i) for i in range(3)]
+        out = {}
+        for mode in ("rccl", "none"):
+            model = build_model(cfg, BaseVocab(), dev, seed=5)
+            red = GradReducer(bucket_mb=0.5, exchange_single=True) if mode == "rccl" else None
+            if red is not None:
+                assert red._avg and red._active and red.world == 1
+            tr = Trainer(model, cfg, num_gpus=1, reducer=red)
+            fired = []
+            for b in batches:
+                tr.step(*b)
+                if red is not None:
+                    fired.append(len(red._fired))
+            torch.cuda.synchronize()
+            out[mode] = {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}
+            if red is not None:
+                # the un-overlapped form of the same exchange on the final gradients: identity at one rank as well
+                g = model._ensure_flat()["g"]
+                before = g.clone()
+                red.reduce_flat(g, list(model._ensure_flat()["offs"]))
+                torch.cuda.synchronize()
+                out["reduce_flat_identity"] = bool(torch.equal(before, g))
+                out["fired"] = fired
+                out["comm_stream"] = red._stream is not None
+        q.put((0, out))
+    except Exception:
+        import traceback
+        q.put((0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_runs_on_one_device_and_is_the_identity_at_world_1():
+    """The `nccl` (= RCCL) branch of GradReducer -- ReduceOp.AVG on bucket slices of the flat gradient, launched from
+    the communication stream after the three producer events, finish() joining it -- executed for real in a one-rank
+    RCCL group on the test GPU: training with the exchange equals training without it bit for bit, several buckets
+    fire per step, and the un-overlapped reduce_flat is the identity too.  (Two ranks on one device are refused by
+    RCCL; the multi-rank arithmetic is covered through gloo above, the ordering by the fake-collective test below.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_worker, args=(0, _free_port(), q))
+    p.start()
+    _, out = q.get(timeout=600)
+    p.join(timeout=60)
+    assert not isinstance(out, str), out
+    assert out["comm_stream"] and out["reduce_flat_identity"]
+    assert all(n > 1 for n in out["fired"]), out["fired"]
+    for n in out["none"]:
+        assert (out["rccl"][n] == out["none"][n]).all(), n
+
+
+def test_overlapped_exchange_is_ordered_after_its_producers(monkeypatch):
+    """Stream / event ordering of the overlapped exchange on one GPU: torch.distributed.all_reduce is replaced by a
+    stand-in that HALVES the slice on the stream it is launched from (from the ordering point of view exactly what a
+    collective is: a kernel on the communication stream that rewrites the bucket).  If a bucket were exchanged before
+    every kernel that adds into it has run (main stream, weight-gradient stream, reduction stream), the late
+    contributions would escape the halving.  Expected: every gradient == 0.5 x the gradient of a run without exchange,
+    bit for bit."""
+    from commu_amd import ddp
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import build_model
+    dev = torch.device("cuda", 0)
+    cfg = _cfg_mid(16)
+    d, t, r, n = synthetic_batch(256, 16, dev, seed=77)
+
+    def grads(red):
+        model = build_model(cfg, BaseVocab(), dev, seed=5)
+        model.eval()                                        # (no dropout: both runs see the same function)
+        model.zero_grad()
+        loss, _ = model(d, t, r, None)
+        if red is not None:
+            red.begin()
+            model.grad_ready_hook = red.range_ready
+        loss.float().mean().backward()
+        model.grad_ready_hook = None
+        g = model._ensure_flat()["g"]
+        if red is not None:
+            red.finish(g)
+        torch.cuda.synchronize()
+        return g.clone()
+
+    ref = grads(None)
+    launches = []
+
+    class _Done:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def fake_all_reduce(tensor, op=None, group=None, async_op=False):
+        launches.append(torch.cuda.current_stream().cuda_stream)
+        tensor.mul_(0.5)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _Done(ev)
+
+    monkeypatch.setattr(ddp.dist, "all_reduce", fake_all_reduce)
+    red = ddp.GradReducer(bucket_mb=0.5)
+    red.world, red._avg, red._active = 2, True, True
+    for _ in range(3):
+        got = grads(red)
+        assert len(red._fired) > 2 and red._stream is not None
+        assert set(launches) == {red._stream.cuda_stream}      # every collective was launched from the communication stream
+        assert torch.equal(got, ref * 0.5)
