@@ -79,7 +79,7 @@ def cpu_baseline(args):
                       f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step)"}
 
 
-def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
+def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
     """Second half of BASELINE.json's metric: autoregressive decode tokens/s.  The timed path is the one the
     generator ships (commu_amd.generate.ForcedDecoder): B sequences in parallel, ONE hipGraph replay per loop
     iteration = forcing decision kernel + K/V-cached decode step + temperature / top-k sampling kernel (top_k 32,
@@ -106,10 +106,17 @@ def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
         uni = torch.rand(B, dec.ld_u).numpy()
         dec.load([meta] * B, [data] * B, uni)
         st = dec.state
-        if klen0 > 11:                  # synthetic long memory: random cache content, lengths set directly
-            st.kc.normal_(0, 0.5)
-            st.vc.normal_(0, 0.5)
-            st.klen.fill_(klen0)
+        if klen0 > 11:
+            # long memory: a REAL prefill of klen0 tokens (the meta context followed by random event tokens) through the
+            # training kernels -- the K/V caches hold what generation would have written, not noise; the forcing state
+            # records keep their own (sequence-length) counters, so only the cache length moves
+            g = torch.Generator().manual_seed(3)
+            ctx = torch.randint(3, 729, (klen0, B), generator=g)
+            ctx[0] = 0
+            ctx[1:11] = torch.tensor(meta[:10])[:, None]
+            st.kc.zero_()
+            st.vc.zero_()
+            st.prefill(ctx.to(dev))
         if graph:
             dec.build_graph()
 
@@ -145,7 +152,7 @@ def decode_bench(dev, args, klen0, steps=128, B=64, graph=True):
                          "bytes_per_step": int(bytes_step)}}
 
 
-def decode_cpu_baseline(args, steps=64):
+def decode_cpu_baseline(args, steps=256):
     """The oracle's generation step (oracle/xl_ref.forward_generate: the reference's forward_generate restated, full
     QKV recomputation over the memory every step) + the oracle's sampling step, batch 1, sequential like the reference
     (midi_inferrer.py:199-237), timed on the host cores at memory length ~1000."""
@@ -393,7 +400,7 @@ def main():
         out["decode"] = {"metric": "autoregressive decode tokens/sec (64 sequences in parallel, device-resident forcing "
                                    "+ K/V-cache step + top-k 32 / T 0.95 sampling in one hipGraph per iteration)",
                          "short_memory": decode_bench(dev, args, 11), "long_memory": decode_bench(dev, args, 1000),
-                         "long_memory_no_graph": decode_bench(dev, args, 1000, steps=64, graph=False)}
+                         "long_memory_no_graph": decode_bench(dev, args, 1000, steps=128, graph=False)}
         if not args.no_cpu_baseline:
             out["decode"]["cpu_baseline"] = decode_cpu_baseline(args)
     if world == 1 and not args.no_cpu_baseline:

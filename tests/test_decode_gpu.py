@@ -303,3 +303,56 @@ def test_token_generation_pipeline_from_reference_arguments(golden_dir):
     assert all(chk.validate_generated_sequence(s) for s in seqs)
     assert not any(chk.validate_generated_sequence(s) for why, s in pipe.rejected if why == "no_note")
 
+
+
+@pytest.mark.parametrize("shape", [(6, 8, 512, 1024), (6, 10, 500, 1000)], ids=["L6_D512_dh64", "L6_D500_dh50"])
+def test_cached_decode_at_long_memory_vs_oracle(shape):
+    """The K/V-cache decode step where the bench times it (bench.py `long_memory`): a REAL prefill of 1000 tokens
+    (the training kernels, model.forward_generate's path), then 16 cached single-token steps, every step compared with
+    oracle.xl_ref.forward_generate, which -- like the reference (model.py:606-628, midi_inferrer.py:199-207) --
+    recomputes the whole memory each step.  Logits <= 2e-2 of their range; greedy tokens exact wherever the oracle's
+    top-1 / top-2 gap exceeds the logit error bound (the gap and the number of such steps are reported); both runs are
+    fed the ORACLE's greedy token so one flipped near-tie cannot derail the comparison."""
+    from commu_amd.generate import DecodeState
+    from oracle import xl_ref as X
+    from test_configs_gpu import build
+    L, H, D, DI = shape
+    B, T0, NSTEP = 2, 1000, 16
+    model, cfg, s, params = build(L, H, D, DI, 1, 4146, seed=41)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    g = torch.Generator().manual_seed(19)
+    ctx = torch.randint(2, 729, (T0, B), generator=g)
+    with torch.no_grad():
+        ref_logits, ref_mems = X.forward_generate(params, s, ctx, None, 4146, True)
+    # the reference-API path at this length
+    logits, mems = model.forward_generate(ctx.to(DEV), None)
+    rng = float(ref_logits.abs().max())
+    assert float((logits.float().cpu() - ref_logits).abs().max()) / rng < 2e-2
+    assert tuple(mems.shape) == tuple(ref_mems.shape)
+    # the cached path
+    st = DecodeState(model, B, T0 + NSTEP + 8)
+    st.prefill(ctx.to(DEV))
+    ones = torch.ones(B, dtype=torch.uint8, device=DEV)
+    tok = ref_logits[-1].argmax(-1)                                  # [B]
+    gaps, checked, worst = [], 0, 0.0
+    for step in range(NSTEP):
+        with torch.no_grad():
+            ref, ref_mems = X.forward_generate(params, s, tok[None], ref_mems, 4146, True)
+        lg = st.step(tok.to(DEV), ones, ones)[:, :729].float().cpu()
+        err = float((lg - ref[0]).abs().max())
+        worst = max(worst, err / rng)
+        assert err / rng < 2e-2, (step, err, rng)
+        top2 = ref[0].topk(2, dim=-1).values
+        for b in range(B):
+            gap = float(top2[b, 0] - top2[b, 1])
+            gaps.append(gap)
+            if gap > 2.5 * err:
+                checked += 1
+                assert int(lg[b].argmax()) == int(ref[0, b].argmax()), (step, b, gap, err)
+        tok = ref[0].argmax(-1)
+    assert int(st.klen[0]) == T0 + NSTEP
+    print(f"long-memory decode {shape}: worst logit error {worst:.2e} of range, min top1-top2 gap {min(gaps):.3f}, "
+          f"{checked}/{len(gaps)} greedy tokens checked exact")
+    assert checked >= len(gaps) // 2
