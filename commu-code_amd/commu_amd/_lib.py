@@ -77,7 +77,6 @@ PROTOTYPES = {
     "commu_adam_step": [c_p, c_p, c_p, c_p, c_p, c_z, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_p],
     "commu_scale_clip_f32": [c_p, c_z, c_p, c_f, c_p],
     "commu_cast_f32_bf16": [c_p, c_p, c_z, c_p],
-    "commu_split_f32_bf16x2": [c_p, c_p, c_p, c_z, c_p],
     "commu_cast_bf16_f32": [c_p, c_p, c_z, c_p],
     "commu_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_transpose_f32_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],

@@ -796,16 +796,12 @@ class MemTransformerLM(nn.Module):
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
                             scratch=scr[i & 1], defer=(defer_last if last else defer) if side is not None else None)
             gWr = gv(pre + "dec_attn.r_net.weight", (HDt, Dt))
-            # dW_r = dRd^T . pos: dRd is a long fp32 sum with heavy cancellation and r_net's gradient is small, so the
-            # fp32 operand goes in as hi + lo bf16 halves (two small GEMMs, side stream) instead of one rounded copy
-            def r_grad(drd=drd, gWr=gWr, ws="slabs"):
-                for part in (ops.split_bf16x2(drd) if getattr(self, "r_grad_split", True) else (ops.cast_bf16(drd),)):
-                    self._tn_acc(part, sv.pd, gWr, crop=spec("r"), ws=ws)
             if side is None:
-                r_grad()
+                self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"))
             else:
                 keep.append(drd)
-                (defer_last if last else defer)(lambda f=r_grad, ws="slabs2" if last else "slabs": f(ws=ws))
+                (defer_last if last else defer)(lambda drd=drd, gWr=gWr, ws="slabs2" if last else "slabs": self._tn_acc(
+                    ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"), ws=ws))
                 scr_free[i & 1] = torch.cuda.Event()
                 scr_free[i & 1].record(side)
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))

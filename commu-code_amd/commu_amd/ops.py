@@ -471,14 +471,6 @@ def cast_bf16(x, out=None):
     return out
 
 
-def split_bf16x2(x):
-    """fp32 x -> (hi, lo) bf16 with hi + lo ~ x to ~16 mantissa bits (two GEMM operands instead of one rounded one)."""
-    hi = torch.empty(x.shape, device=x.device, dtype=BF16)
-    lo = torch.empty(x.shape, device=x.device, dtype=BF16)
-    call("commu_split_f32_bf16x2", _p(x), _p(hi), _p(lo), x.numel(), _s())
-    return hi, lo
-
-
 def cast_f32(x, out=None):
     out = torch.empty(x.shape, device=x.device, dtype=F32) if out is None else out
     call("commu_cast_bf16_f32", _p(x), _p(out), x.numel(), _s())

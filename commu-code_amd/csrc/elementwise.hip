@@ -650,15 +650,6 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = f2bf(in[i]);
 }
-// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 GEMM operands that together carry ~16 mantissa bits
-__global__ void split_f32_bf16x2_kernel(const float* __restrict__ in, bf16* __restrict__ hi, bf16* __restrict__ lo, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = in[i];
-        const bf16 h = f2bf(x);
-        hi[i] = h;
-        lo[i] = f2bf(x - bf2f(h));
-    }
-}
 __global__ void cast_bf16_f32_kernel(const bf16* __restrict__ in, float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = bf2f(in[i]);
@@ -924,14 +915,6 @@ extern "C" int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStre
     if (n == 0) return 0;
     COMMU_LAUNCH(cast_f32_bf16_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, in,
                        (bf16*)out, n);
-    COMMU_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int commu_split_f32_bf16x2(const float* in, void* hi, void* lo, size_t n, hipStream_t stream) {
-    if (n == 0) return 0;
-    COMMU_LAUNCH(split_f32_bf16x2_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream, in, (bf16*)hi,
-                 (bf16*)lo, n);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

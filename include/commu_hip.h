@@ -190,8 +190,6 @@ int commu_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, 
 int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, float clip, hipStream_t stream);
 int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
 int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream);
-/* in = hi + lo, hi = bf16(in), lo = bf16(in - hi): fp32 GEMM operand as two bf16 ones (r_net weight gradient) */
-int commu_split_f32_bf16x2(const float* in, void* hi, void* lo, size_t n, hipStream_t stream);
 int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, int cols, hipStream_t stream);
 int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
                              hipStream_t stream);

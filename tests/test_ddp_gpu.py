@@ -171,7 +171,7 @@ def _rccl_single_worker(rank, port, q):
 def test_rccl_branch_runs_on_one_device_and_is_the_identity_at_world_1():
     """The `nccl` (= RCCL) branch of GradReducer -- ReduceOp.AVG on bucket slices of the flat gradient, launched from
     the communication stream after the three producer events, finish() joining it -- executed for real in a one-rank
-    RCCL group on the test GPU: training with the exchange equals training without it bit for bit, several buckets
+    RCCL group on the test GPU: training with the exchange equals training without it (to fp32 summation-order noise), several buckets
     fire per step, and the un-overlapped reduce_flat is the identity too.  (Two ranks on one device are refused by
     RCCL; the multi-rank arithmetic is covered through gloo above, the ordering by the fake-collective test below.)"""
     ctx = mp.get_context("spawn")
@@ -183,8 +183,11 @@ def test_rccl_branch_runs_on_one_device_and_is_the_identity_at_world_1():
     assert not isinstance(out, str), out
     assert out["comm_stream"] and out["reduce_flat_identity"]
     assert all(n > 1 for n in out["fired"]), out["fired"]
+    # (not bit for bit: the bias / LayerNorm-parameter column sums end in fp32 atomics, whose order differs run to run)
+    import numpy as np
     for n in out["none"]:
-        assert (out["rccl"][n] == out["none"][n]).all(), n
+        a, b = out["rccl"][n], out["none"][n]
+        assert np.abs(a - b).max() <= 1e-6 + 1e-4 * np.abs(b).max(), (n, float(np.abs(a - b).max()))
 
 
 def test_overlapped_exchange_is_ordered_after_its_producers(monkeypatch):
@@ -192,14 +195,15 @@ def test_overlapped_exchange_is_ordered_after_its_producers(monkeypatch):
     stand-in that HALVES the slice on the stream it is launched from (from the ordering point of view exactly what a
     collective is: a kernel on the communication stream that rewrites the bucket).  If a bucket were exchanged before
     every kernel that adds into it has run (main stream, weight-gradient stream, reduction stream), the late
-    contributions would escape the halving.  Expected: every gradient == 0.5 x the gradient of a run without exchange,
-    bit for bit."""
+    contributions would escape the halving.  Expected: every gradient == 0.5 x the gradient of a run without exchange
+    (to the summation-order noise of the column-sum atomics)."""
     from commu_amd import ddp
     from commu_amd.model.dataset import BaseVocab, synthetic_batch
     from commu_amd.train import build_model
     dev = torch.device("cuda", 0)
     cfg = _cfg_mid(16)
     d, t, r, n = synthetic_batch(256, 16, dev, seed=77)
+    model_offsets = {}
 
     def grads(red):
         model = build_model(cfg, BaseVocab(), dev, seed=5)
@@ -211,10 +215,13 @@ def test_overlapped_exchange_is_ordered_after_its_producers(monkeypatch):
             model.grad_ready_hook = red.range_ready
         loss.float().mean().backward()
         model.grad_ready_hook = None
-        g = model._ensure_flat()["g"]
+        fl = model._ensure_flat()
+        g = fl["g"]
         if red is not None:
             red.finish(g)
         torch.cuda.synchronize()
+        for (n, p_), off in zip(model.named_parameters(), fl["offs"]):
+            model_offsets[n] = (off, off + p_.numel())
         return g.clone()
 
     ref = grads(None)
@@ -241,4 +248,7 @@ def test_overlapped_exchange_is_ordered_after_its_producers(monkeypatch):
         got = grads(red)
         assert len(red._fired) > 2 and red._stream is not None
         assert set(launches) == {red._stream.cuda_stream}      # every collective was launched from the communication stream
-        assert torch.equal(got, ref * 0.5)
+        # (to the summation-order noise of the atomics in the column-sum kernels; an escaped contribution is O(1) of it)
+        for name, off in model_offsets.items():
+            a, b = got[off[0]:off[1]], ref[off[0]:off[1]] * 0.5
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, name

@@ -177,9 +177,14 @@ def test_g8_optimizer_steps_vs_reference(golden_dir):
     allu, allr = torch.cat(allu), torch.cat(allr)
     total = float(torch.dot(allu, allr) / (allu.norm() * allr.norm()))
     _dump("g8", {"cos": cos, "total": total, "norm_ratio": float(allu.norm() / allr.norm())})
-    assert total > 0.97, total
+    assert total > 0.99, total
     assert abs(float(allu.norm() / allr.norm()) - 1.0) < 0.03
-    assert min(cos.values()) > 0.8, cos
+    # per tensor: >= 0.99 everywhere except r_net.weight (>= 0.8).  Its GRADIENT is as accurate as the others' (1 % of
+    # its range: test_g1_*), but most of its elements lie below the bf16 rounding noise of dS, and Adam turns every
+    # coordinate into a step of size ~lr whatever its magnitude -- measured 0.85 / 0.92; feeding the r_net weight-
+    # gradient GEMM an fp32-accurate (hi + lo bf16) dRd instead of the rounded copy changed neither (0.856 / 0.924).
+    for k, v in cos.items():
+        assert v > (0.8 if k.endswith("r_net.weight") else 0.99), (k, v)
 
 
 def test_state_dict_roundtrip_and_no_cpu_path(golden_dir):
