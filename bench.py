@@ -212,7 +212,7 @@ def pmc_traffic(kernel, args):
     return None
 
 
-def train_bench(args, dev, world, rank, steps, warmup):
+def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     """W untimed + K timed optimiser steps of the shape in `args`; returns (elapsed seconds (max over ranks),
     tokens per step per rank, per-entry-point HIP-event times) -- None on ranks other than 0."""
     from commu_amd import _lib
@@ -235,7 +235,8 @@ def train_bench(args, dev, world, rank, steps, warmup):
     if reducer is not None:
         reducer.broadcast_params(model)
     trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer)
-    batches = [synthetic_batch(args.tgt_len, B, dev, seed=cfg.TRAIN.seed + 1000 * rank + i) for i in range(4)]
+    batches = [synthetic_batch(args.tgt_len, B, dev, seed=cfg.TRAIN.seed + 1000 * rank + i, reset_prob=reset_prob)
+               for i in range(4)]
     tokens_per_step = sum(b[3] for b in batches) // len(batches)
 
     def run(nsteps, base, sample_events=False):
@@ -296,6 +297,70 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
             "event_sampling": "every 4th step of the timed region"}
 
 
+def iterator_bench(args, dev, steps, warmup, resident_ms):
+    """The same optimiser steps fed by the batch producer instead of HBM-resident batches (the reference's tokens/s
+    includes data loading, train.py:171-186): a synthetic ragged corpus is WRITTEN in the reference's on-disk format
+    (input_/target_{train,val}.npy object arrays: 11 meta tokens, int16 events ending in EOS; preprocessor.py:161-162,
+    dataset.py:74-87), read back by ComMUDataset and streamed through get_iterator (epoch scheduler, vectorised
+    gather into pinned buffers on a worker thread, asynchronous H2D copies) into Trainer.step.  Reports the reference's
+    metric (non-pad target tokens/s), the step time against the resident-batch step time of this run, and how long the
+    training loop waited for the producer."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, ComMUDataset
+    from commu_amd.train import Trainer, build_model
+    T, B = args.tgt_len, args.batch_per_gpu
+    rng = np.random.default_rng(1111)
+    tmp = tempfile.mkdtemp(prefix="commu_bench_npy_")
+    try:
+        for tag, nseq in (("train", max(600, 4 * B)), ("val", B + 8)):
+            lens = rng.integers(T // 2, 3 * T, size=nseq)
+            metas = np.empty(nseq, dtype=object)
+            events = np.empty(nseq, dtype=object)
+            for i, n in enumerate(lens):
+                metas[i] = np.array(rng.integers(560, 729, size=11), dtype=object)
+                ev = rng.integers(2, 560, size=int(n)).astype(np.int16)
+                ev[-1] = 1
+                events[i] = ev
+            np.save(os.path.join(tmp, f"input_{tag}.npy"), metas, allow_pickle=True)
+            np.save(os.path.join(tmp, f"target_{tag}.npy"), events, allow_pickle=True)
+        cfg = get_cfg(num_layers=args.layers, num_heads=args.heads, units=args.d_model, inner_size=args.d_inner,
+                      tgt_length=T, mem_length=args.mem_len, batch_size=B, batch_chunk=args.batch_chunk,
+                      dropout=args.dropout, attention_dropout=args.dropout)
+        ds = ComMUDataset(tmp, cfg)
+        model = build_model(cfg, BaseVocab(), dev, seed=cfg.TRAIN.seed)
+        model.train()
+        trainer = Trainer(model, cfg, num_gpus=1, reducer=None)
+        it = ds.get_iterator(B, T, dev, "train", True, seed=cfg.TRAIN.seed)()
+        for _ in range(warmup):
+            trainer.step(*next(it))
+        torch.cuda.synchronize()
+        wait, tokens = 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tw = time.perf_counter()
+            d, t, r, n = next(it)
+            wait += time.perf_counter() - tw
+            trainer.step(d, t, r, n)
+            tokens += n
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        it.close()
+        del trainer, model
+        torch.cuda.empty_cache()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    ms = 1e3 * elapsed / steps
+    return {"value": round(tokens / elapsed, 1), "unit": "non-pad target tokens/s", "ms_per_step": round(ms, 3),
+            "slot_tokens_per_s": round(T * B * steps / elapsed, 1), "fill": round(tokens / (T * B * steps), 4),
+            "producer_wait_ms_per_step": round(1e3 * wait / steps, 4),
+            "step_rate_vs_resident_batches": round(resident_ms / ms, 4), "steps": steps, "warmup": warmup,
+            "corpus": "synthetic ragged (lengths uniform in [T/2, 3T)), on-disk .npy object arrays, shuffled epochs"}
+
+
 # Further single-GPU rows (VERDICT r1: the shapes that were parity-tested but never timed); a few steps each
 EXTRA_ROWS = [
     # tag, overrides
@@ -324,6 +389,16 @@ def extra_rows(args, dev):
                      "steps": steps, "warmup": warmup, "tokens_per_step": tps,
                      "step_mfma_frac": round(f / (elapsed / steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
                      "roofline": attention_roofline(a, prof, tps, elapsed, pscale)}
+        if a.mem_len > 0 and not getattr(a, "fp8_forward", False):
+            # reset_mems ~ Bernoulli(T / avg_len), avg_len = 512 (capped at 1), so that the reset
+            # path (memory tiles skipped per column, zero-filled distances in the backward) is inside a timed region;
+            # the row above, without resets, attends to the whole memory in every column (the heavier case)
+            pr = min(1.0, a.tgt_len / 512.0)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            e2, tps2, _, _ = train_bench(a, dev, 1, 0, steps, warmup, reset_prob=pr)
+            rows[tag]["with_resets"] = {"reset_prob": pr, "value": round(tps2 * steps / e2, 1),
+                                        "ms_per_step": round(1e3 * e2 / steps, 3)}
     return rows
 
 
@@ -349,6 +424,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU shape rows")
     ap.add_argument("--fp8-forward", dest="fp8_forward", action="store_true",
                     help="forward Linear products of the layers in MX-fp8 (opt-in; bf16 is the default and the headline)")
+    ap.add_argument("--from-iterator", dest="from_iterator", action="store_true",
+                    help="also time the step fed by ComMUDataset.get_iterator from an on-disk .npy corpus (on by default "
+                         "with the extra rows)")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="weight-gradient work on the main stream (default: a side stream)")
     args = ap.parse_args()
@@ -394,6 +472,8 @@ def main():
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
         "roofline": attention_roofline(args, prof, tokens_per_step, elapsed, pscale),
     }
+    if world == 1 and (args.from_iterator or not args.no_extra):
+        out["iterator_fed"] = iterator_bench(args, dev, args.steps, args.warmup, ms_per_step)
     if world == 1 and not args.no_extra:
         out["extra_rows"] = extra_rows(args, dev)
     if world == 1 and not args.no_decode:

@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
         }
         __builtin_amdgcn_wave_barrier();
         // flush: row r (distance dl = i + M - j0 at jj = 0) completed the aligned chunks 8c in [dl - 63, dl]
-        if (a.dsk_wedge != -7) {
+        {
             // lane (row = lane >> 2, k = lane & 3): chunks c = c0 + k and c0 + k + 4 of its row; the row's part of the address
             // (fl_row) is per query tile, the descriptor is per head, a false predicate becomes an out-of-range offset
             const int dl0 = fl_i + M - j0;

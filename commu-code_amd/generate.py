@@ -43,24 +43,83 @@ def parse_args():
     input_arg_parser.add_argument("--temperature", type=float, default=0.95)
     # not in the reference (which retries rejected sequences forever, midi_inferrer.py:342-353): bound the retries
     input_arg_parser.add_argument("--max_rounds", type=int, default=None)
+    # not in the reference: replicas of the generator, one per GPU (default: every visible GPU, at most num_generate)
+    input_arg_parser.add_argument("--gpus", type=int, default=None)
     return {"model_args": model_arg_parser, "input_args": input_arg_parser}
 
 
-def main(model_args, input_args, training_cfg=None):
+def split_num_generate(num_generate, n_replicas):
+    """Shares of `num_generate` for `n_replicas` independent replicas (first ones take the remainder)."""
+    n_replicas = max(1, min(int(n_replicas), int(num_generate)))
+    base, rem = divmod(int(num_generate), n_replicas)
+    return [base + (1 if r < rem else 0) for r in range(n_replicas)]
+
+
+def generate_on_device(model_args, in_args, device_index, num_generate, uniform_seed, max_rounds, training_cfg=None):
+    """One replica: checkpoint -> model on cuda:<device_index>, `num_generate` validated sequences."""
+    import copy
+
     import torch
     from commu_amd.midi_generator.meta import PreprocessTask
     from commu_amd.midi_generator.midi_inferrer import InferenceTask
     from commu_amd.midi_generator.model_initializer import ModelInitializeTask
-    device = torch.device("cuda")
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     init = ModelInitializeTask(model_args, map_location="cpu", device=device, training_cfg=training_cfg)
     model = init.execute()
     pre = PreprocessTask()
+    args = copy.deepcopy(in_args)
+    args["num_generate"] = num_generate
+    encoded_meta = pre.execute(args)
+    task = InferenceTask(device)
+    task.uniform_seed = uniform_seed
+    task(model=model, input_data=pre.input_data, inference_cfg=init.inference_cfg)
+    return encoded_meta, task.execute(encoded_meta, max_rounds=max_rounds)
+
+
+def _replica(rank, device_index, model_args, in_args, share, max_rounds, training_cfg, q):
+    try:
+        # distinct variates per replica: 1_000_003 apart (a replica's rounds / sequences use seed + 7919 r + b)
+        q.put((rank, generate_on_device(model_args, in_args, device_index, share, 1_000_003 * rank, max_rounds,
+                                        training_cfg)))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def main(model_args, input_args, training_cfg=None, device_indices=None):
+    """`num_generate` sequences are independent (the reference produces them one after the other,
+    midi_inferrer.py:338-354): with several GPUs visible they are split across them as REPLICAS -- one process per
+    GPU, each with its own model copy and its share, no collective -- and concatenated in
+    device order.  --gpus 1 (or one visible device) keeps everything in this process.  `device_indices` (tests):
+    explicit device of every replica, e.g. [0, 0] = two replica processes on the one GPU of a test box."""
+    import torch
     in_args = dict(vars(input_args))
     max_rounds = in_args.pop("max_rounds", None)
-    encoded_meta = pre.execute(in_args)
-    task = InferenceTask(device)
-    task(model=model, input_data=pre.input_data, inference_cfg=init.inference_cfg)
-    sequences = task.execute(encoded_meta, max_rounds=max_rounds)
+    gpus = in_args.pop("gpus", None)
+    if device_indices is None:
+        n_vis = torch.cuda.device_count()
+        device_indices = list(range(max(1, n_vis if gpus is None else min(gpus, n_vis))))
+    shares = split_num_generate(in_args["num_generate"], len(device_indices))
+    if len(shares) == 1:
+        encoded_meta, sequences = generate_on_device(model_args, in_args, device_indices[0], shares[0], 0, max_rounds,
+                                                     training_cfg)
+    else:
+        import torch.multiprocessing as mp
+        ctx = mp.get_context("spawn")          # (never fork / exec a process that has initialised the GPU)
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_replica, args=(r, device_indices[r], model_args, in_args, share, max_rounds,
+                                                    training_cfg, q)) for r, share in enumerate(shares)]
+        for p_ in procs:
+            p_.start()
+        results = dict(q.get() for _ in procs)
+        for p_ in procs:
+            p_.join()
+        bad = [v for v in results.values() if isinstance(v, str)]
+        if bad:
+            raise RuntimeError("generation replica failed:\n" + bad[0])
+        encoded_meta = results[0][0]
+        sequences = [seq for r in range(len(shares)) for seq in results[r][1]]
     os.makedirs(input_args.output_dir, exist_ok=True)
     with open(os.path.join(input_args.output_dir, "sequences.json"), "w") as f:
         json.dump({"encoded_meta": encoded_meta, "sequences": sequences}, f)

@@ -277,3 +277,19 @@ def test_abandoned_iterator_releases_its_prefetch_thread():
     while threading.active_count() > before and time.time() < deadline:
         time.sleep(0.05)
     assert threading.active_count() <= before
+
+
+@pytest.mark.parametrize("over,frag", [
+    (dict(units=1024, num_heads=8), "d_head <= 64"),          # d_head 128
+    (dict(units=2048, num_heads=32), "d_model <= 1024"),
+    (dict(units=130, num_heads=2), "d_model % 4 == 0"),
+])
+def test_unsupported_shapes_raise_with_the_supported_list(over, frag):
+    """Shapes the reference accepts (model.py:429-444 has no limits) and this build does not: refused at construction
+    with an error that lists what IS supported ("Supported shapes")."""
+    from commu_amd._lib import CommuHipError
+    from commu_amd.model.model import MemTransformerLM
+    cfg = get_cfg(inner_size=256, tgt_length=16, mem_length=0, **over)
+    with pytest.raises(CommuHipError) as e:
+        MemTransformerLM(cfg, BaseVocab())
+    assert frag in str(e.value) and "unsupported shape" in str(e.value)

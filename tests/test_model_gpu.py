@@ -434,6 +434,14 @@ def test_generate_cli_from_a_reference_checkpoint(golden_dir, tmp_path):
     out = json.load(open(tmp_path / "out" / "sequences.json"))
     assert out["encoded_meta"] == [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
     assert out["sequences"] == seqs and len(seqs) <= 2          # a random model rarely passes both validators
+    # replicas (num_generate split across GPUs, no collective): two replica PROCESSES, both on the
+    # test box's one GPU, shares 2 + 1
+    assert cli.split_num_generate(3, 2) == [2, 1] and cli.split_num_generate(2, 8) == [1, 1]
+    iargs.num_generate = 3
+    seqs2 = cli.main(margs, iargs, training_cfg=_g10_cfg(z, False), device_indices=[0, 0])
+    out2 = json.load(open(tmp_path / "out" / "sequences.json"))
+    assert out2["sequences"] == seqs2 and len(seqs2) <= 3
+    assert out2["encoded_meta"] == out["encoded_meta"]
 
 
 @pytest.mark.gpu
