@@ -126,8 +126,11 @@ def gather_batch(corpus, seq, pos, cnt, bptt, data, target, pad):
 
 
 class _Prefetcher:
-    """Fills a small ring of (pinned) host batches on a worker thread; the consumer turns them into device tensors
-    with asynchronous copies.  A slot is refilled only after the copy out of it has completed."""
+    """A worker thread fills a small ring of (pinned) host batches AND ships them: every batch goes to the GPU by an
+    asynchronous copy on a dedicated COPY STREAM, issued by the worker itself, two batches ahead of the consumer.
+    (Copies enqueued on the training stream -- the first version -- only run once that stream has drained the step in
+    front of them: the ring then recycles at the pace of the GPU and the training loop waits for its own queue.)  The
+    consumer makes its stream wait for the copy's event; a pinned slot is refilled once its copy has completed."""
 
     DEPTH = 3
 
@@ -139,25 +142,35 @@ class _Prefetcher:
             bufs = [torch.empty(shape, dtype=dtype, pin_memory=self.cuda) for shape, dtype in shapes]
             self.slots.append({"bufs": bufs, "event": None})
         self.ready = queue.Queue(maxsize=self.DEPTH - 1)
-        self.idle = queue.Queue()
-        for i in range(self.DEPTH):
-            self.idle.put(i)
         self.stop = False
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.thread = threading.Thread(target=self._work, args=(produce,), daemon=True)
         self.thread.start()
 
     def _work(self, produce):
         try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            i = 0
             while not self.stop:
-                i = self.idle.get()
-                if i is None:
-                    return
                 slot = self.slots[i]
+                i = (i + 1) % self.DEPTH
                 if slot["event"] is not None:
                     slot["event"].synchronize()                   # the copy out of this slot has finished
                 extra = produce(slot["bufs"])
-                if not self._put(None if extra is None else (i, extra)) or extra is None:
-                    return                                        # closed, or end of the stream
+                if extra is None:                                 # end of the stream
+                    self._put(None)
+                    return
+                if self.cuda:
+                    with torch.cuda.stream(self.copy_stream):
+                        out = [b.to(self.device, non_blocking=True) for b in slot["bufs"]]
+                        ev = torch.cuda.Event()
+                        ev.record(self.copy_stream)
+                    slot["event"] = ev
+                else:
+                    out, ev = [b.clone() for b in slot["bufs"]], None
+                if not self._put((out, ev, extra)):
+                    return
         except BaseException as exc:                              # surfaced in the consumer
             self._put(exc)
 
@@ -181,24 +194,20 @@ class _Prefetcher:
             raise StopIteration
         if isinstance(item, BaseException):
             raise item
-        i, extra = item
-        slot = self.slots[i]
-        if self.cuda:
-            out = [b.to(self.device, non_blocking=True) for b in slot["bufs"]]
-            slot["event"] = torch.cuda.Event()
-            slot["event"].record()
-        else:
-            out = [b.clone() for b in slot["bufs"]]
-        self.idle.put(i)
+        out, ev, extra = item
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in out:
+                t.record_stream(cur)                              # allocated on the copy stream, used on this one
         return out, extra
 
     def close(self):
         self.stop = True
-        self.idle.put(None)
         try:                                                      # unblock a worker waiting on a full queue
             while True:
                 self.ready.get_nowait()
-        except queue.Empty:
+        except Exception:                                         # queue.Empty (may already be torn down at exit)
             pass
         if self.thread is not threading.current_thread():
             self.thread.join(timeout=2.0)
