@@ -234,7 +234,10 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     reducer = GradReducer() if world > 1 else None
     if reducer is not None:
         reducer.broadcast_params(model)
-    trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer)
+    use_graph = getattr(args, "graph", None)
+    if use_graph is None:
+        use_graph = (B // args.batch_chunk) * args.tgt_len <= 16384
+    trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer, graph=use_graph)
     batches = [synthetic_batch(args.tgt_len, B, dev, seed=cfg.TRAIN.seed + 1000 * rank + i, reset_prob=reset_prob)
                for i in range(4)]
     tokens_per_step = sum(b[3] for b in batches) // len(batches)
@@ -243,8 +246,12 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
         for i in range(nsteps):
             if sample_events:          # HIP events around the profiled entry points on every fourth step only
                 _lib.profile_enable(i % 4 == 0)
+                # (hipGraph mode: a replay has no per-call hooks, so the sampled steps run EAGERLY -- same kernels, same
+                #  streams -- and the other three quarters of the timed region are graph replays)
+                trainer.graph_mode = use_graph and i % 4 != 0
             d, t, r, n = batches[(base + i) % len(batches)]
             trainer.step(d, t, r, n)
+        trainer.graph_mode = use_graph
 
     run(warmup, 0)
     torch.cuda.synchronize()
@@ -424,6 +431,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU shape rows")
     ap.add_argument("--fp8-forward", dest="fp8_forward", action="store_true",
                     help="forward Linear products of the layers in MX-fp8 (opt-in; bf16 is the default and the headline)")
+    ap.add_argument("--graph", dest="graph", action=argparse.BooleanOptionalAction, default=None,
+                    help="replay the optimiser step from hipGraphs (Trainer(graph=True)); --no-graph: eager launches; "
+                         "default: graphs when a micro-batch has <= 16384 tokens (there the eager step is bound by the "
+                         "host's launch rate; at the headline shape the eager step with its side streams is faster)")
     ap.add_argument("--from-iterator", dest="from_iterator", action="store_true",
                     help="also time the step fed by ComMUDataset.get_iterator from an on-disk .npy corpus (on by default "
                          "with the extra rows)")
@@ -467,6 +478,8 @@ def main():
         "config": {"workload": f"transformer-xl train step L{L} D{D} H{H} DI{DI} tgt_len{T} mem_len{M} vocab729",
                    "global_batch": B * world, "batch_per_gpu": B, "batch_chunk": args.batch_chunk, "seq_len": T,
                    "dropout": args.dropout, "parallelism": f"dp{world}", "optimizer": "clip1.0+Adam+invsqrt-LR",
+                   "launch": ("hipGraph replay (every 4th timed step eager, for the per-kernel events)"
+                              if (args.graph if args.graph is not None else (B // args.batch_chunk) * T <= 16384) else "eager"),
                    "weights": "random init (train.py:291-342)"},
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "commu_loss_grad": [c_p, c_i, c_i, c_p, c_f, c_p, c_p],
     "commu_grad_norm": [c_p, c_z, c_p, c_i, c_p, c_p],
     "commu_adam_step": [c_p, c_p, c_p, c_p, c_p, c_z, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_p],
+    "commu_adam_step_dev": [c_p, c_p, c_p, c_p, c_p, c_z, c_p, c_f, c_f, c_f, c_p, c_f, c_p],
+    "commu_adam_bias_corrections": [c_f, c_f, c_i, c_p],
+    "commu_set_seed_salt": [c_p, c_p],
     "commu_scale_clip_f32": [c_p, c_z, c_p, c_f, c_p],
     "commu_cast_f32_bf16": [c_p, c_p, c_z, c_p],
     "commu_cast_bf16_f32": [c_p, c_p, c_z, c_p],
@@ -100,12 +103,13 @@ PROTOTYPES = {
     "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
+    "commu_pack_batch": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_p, c_p],
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
-            "commu_gemm_nt_signbits_words": C.c_longlong}
+            "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
 _NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
-            "commu_forcing_state_ints", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words"}
+            "commu_forcing_state_ints", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
 
 _lib = None
 

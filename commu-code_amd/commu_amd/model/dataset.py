@@ -49,7 +49,7 @@ class _Corpus:
 
     def __init__(self, arrays, pad):
         lens = np.array([len(a) + 1 for a in arrays], dtype=np.int64)
-        self.offsets = np.concatenate([[0], np.cumsum(lens)])
+        self.offsets = np.ascontiguousarray(np.concatenate([[0], np.cumsum(lens)]), dtype=np.int64)
         self.tokens = np.full(int(self.offsets[-1]) + 1, pad, dtype=np.int64)          # (+1: gathers may touch one past the end)
         for s, a in enumerate(arrays):
             self.tokens[self.offsets[s] + 1:self.offsets[s + 1]] = np.asarray(a, dtype=np.int64)
@@ -115,14 +115,19 @@ def schedule_epoch(lens, order, batch_size, bptt):
 
 def gather_batch(corpus, seq, pos, cnt, bptt, data, target, pad):
     """data[:cnt[c], c] = sequence seq[c] from pos[c]; target = the same shifted by one; pad elsewhere.
-    One fancy-index gather per tensor; `data` / `target` are preallocated [bptt, B] int64 numpy views."""
-    base = np.where(seq >= 0, corpus.offsets[np.maximum(seq, 0)] + pos, 0)
-    rows = np.arange(bptt, dtype=np.int64)[:, None]
-    live = rows < cnt[None, :]
-    idx = np.where(live, base[None, :] + rows, 0)
-    np.copyto(data, np.where(live, corpus.tokens[idx], pad))
-    np.copyto(target, np.where(live, corpus.tokens[idx + 1], pad))
-    return int(cnt.sum())
+    ONE native call (commu_pack_batch, csrc/pack.hip -- host code of the C-ABI library), which runs without the GIL:
+    `data` / `target` are preallocated C-contiguous [bptt, B] int64 numpy views."""
+    from .. import _lib
+    seq = np.ascontiguousarray(seq, dtype=np.int64)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    cnt = np.ascontiguousarray(cnt, dtype=np.int64)
+    assert data.flags["C_CONTIGUOUS"] and target.flags["C_CONTIGUOUS"] and data.dtype == np.int64 == target.dtype
+    assert data.shape == (bptt, len(seq)) == target.shape and corpus.tokens.dtype == np.int64
+    n = _lib.call("commu_pack_batch", corpus.tokens.ctypes.data, corpus.offsets.ctypes.data, seq.ctypes.data,
+                  pos.ctypes.data, cnt.ctypes.data, len(seq), bptt, int(pad), data.ctypes.data, target.ctypes.data)
+    if n < 0:
+        raise _lib.CommuHipError(f"commu_pack_batch failed with status {n}")
+    return int(n)
 
 
 class _Prefetcher:

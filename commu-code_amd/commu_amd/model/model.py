@@ -470,7 +470,10 @@ class MemTransformerLM(nn.Module):
         # K16 dropout: active in train() mode; one base seed per forward call, one derived seed per site
         p = float(self.drop.p) if self.training else 0.0
         patt = float(lay[0].dec_attn.dropatt.p) if (self.training and L > 0) else 0.0
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p > 0 or patt > 0) else 0
+        seed = 0
+        if p > 0 or patt > 0:          # (`fixed_drop_seed`: tests pin the base seed; default: torch's CPU generator)
+            fixed = getattr(self, "fixed_drop_seed", None)
+            seed = int(fixed) if fixed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
         def ss(site):
             return ops.site_seed(seed, site)

@@ -459,6 +459,25 @@ def adam_step(p, g, m, v, p_bf16, lr, step, gnorm=None, clip=0.0, beta1=0.9, bet
          _p(gnorm), clip, _s())
 
 
+def adam_step_dev(p, g, m, v, p_bf16, scal, gnorm=None, clip=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_step with {lr, 1 - beta1^t, 1 - beta2^t} read from the device tensor `scal` (fp32 [>= 3]): graph-replayable."""
+    assert scal.dtype == F32 and scal.numel() >= 3
+    call("commu_adam_step_dev", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(scal), beta1, beta2, eps,
+         _p(gnorm), clip, _s())
+
+
+def adam_bias_corrections(beta1, beta2, step):
+    """(1 - beta1^step, 1 - beta2^step) in the library's own float arithmetic (bit-identical to commu_adam_step's)."""
+    out = (C.c_float * 2)()
+    call("commu_adam_bias_corrections", float(beta1), float(beta2), int(step), out)
+    return float(out[0]), float(out[1])
+
+
+def set_seed_salt(src):
+    """Every dropout site adds the uint32 at device tensor `src` (int32 [1]) to its seed from now on (None: back to 0)."""
+    call("commu_set_seed_salt", _p(src), _s())
+
+
 def scale_clip(g, gnorm, clip):
     """g *= min(1, clip / (gnorm + 1e-6))   (torch.nn.utils.clip_grad_norm_, train.py:159-161)"""
     call("commu_scale_clip_f32", _p(g), g.numel(), _p(gnorm), clip, _s())

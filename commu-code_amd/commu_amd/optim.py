@@ -58,6 +58,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.model = model
         self.step_count = 0
         self._pending_clip = None
+        self.dev_scalars = None          # fp32 device tensor {lr, 1 - b1^t, 1 - b2^t}: see step()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,12 +67,19 @@ class FusedAdam(torch.optim.Optimizer):
             fl["m"] = torch.zeros_like(fl["p"])
             fl["v"] = torch.zeros_like(fl["p"])
         grp = self.param_groups[0]
-        self.step_count += 1
         clip = self._pending_clip
         self._pending_clip = None
-        ops.adam_step(fl["p"], fl["g"], fl["m"], fl["v"], fl["bf16"], float(grp["lr"]), self.step_count,
-                      gnorm=fl["gnorm"] if clip is not None else None, clip=clip or 0.0,
-                      beta1=grp["betas"][0], beta2=grp["betas"][1], eps=grp["eps"])
+        if self.dev_scalars is not None:
+            # graph-replayable form: lr and the bias corrections come from device memory (the owner of the graph writes
+            # them -- and advances step_count -- before every replay: Trainer._graph_step)
+            ops.adam_step_dev(fl["p"], fl["g"], fl["m"], fl["v"], fl["bf16"], self.dev_scalars,
+                              gnorm=fl["gnorm"] if clip is not None else None, clip=clip or 0.0,
+                              beta1=grp["betas"][0], beta2=grp["betas"][1], eps=grp["eps"])
+        else:
+            self.step_count += 1
+            ops.adam_step(fl["p"], fl["g"], fl["m"], fl["v"], fl["bf16"], float(grp["lr"]), self.step_count,
+                          gnorm=fl["gnorm"] if clip is not None else None, clip=clip or 0.0,
+                          beta1=grp["betas"][0], beta2=grp["betas"][1], eps=grp["eps"])
         self.model._refresh_shadows(cast=False)
         fl["version"] = sum(p._version for p in fl["params"])
 

@@ -63,8 +63,17 @@ def build_model(cfg, vocab, device, seed=None):
 class Trainer:
     """One rank of the data-parallel training job (train.py:441-473 + train() :113-169)."""
 
-    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0):
+    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0, graph=False):
+        """graph=True: once the step's shapes are steady (XL memory at its full length) the device work of a step is
+        captured in two hipGraphs -- [all micro-batches forward + backward] and [clip + Adam + weight shadows] -- and
+        replayed; the gradient exchange of a multi-GPU job runs between the two replays.  See _graph_step."""
         self.model, self.cfg, self.num_gpus, self.reducer, self.pad_id = model, cfg, num_gpus, reducer, pad_id
+        self.graph_mode = bool(graph)
+        self._graphs = None
+        self._graph_key = None
+        self.graph_failed = None          # reason the capture was given up (then the step stays eager, in this process)
+        # dropout salt of a replayed step (the seed arguments are frozen in the graph): torch's CPU generator, no device sync
+        self.salt_source = lambda: int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         local_lr = cfg.TRAIN.lr / num_gpus                                  # train.py:441
         self.optimizer = FusedAdam(model, lr=local_lr, weight_decay=cfg.TRAIN.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(
@@ -79,6 +88,8 @@ class Trainer:
 
     def step(self, data, target, reset_mems, batch_token_num):
         """train.py:131-169 for one batch; returns the summed micro-batch loss (device tensor)."""
+        if self.graph_mode and self.graph_failed is None and self._graph_ready(data, reset_mems):
+            return self._graph_step(data, target, reset_mems, batch_token_num)
         cfg, model = self.cfg, self.model
         chunk = cfg.TRAIN.batch_chunk
         model.temperature = 1.0
@@ -90,7 +101,12 @@ class Trainer:
         overlap = self.reducer is not None and getattr(model, "grad_mode", "") == "direct"
         for i in range(chunk):
             d, t, r = data_chunks[i].contiguous(), target_chunks[i].contiguous(), reset_chunks[i].contiguous()
-            loss, self.mems[i] = model(d, t, r, self.mems[i])
+            loss, new_mems = model(d, t, r, self.mems[i])
+            if self._graphs is not None and self._graph_state["mems"][i] is not None and new_mems is not None \
+                    and new_mems.shape == self._graph_state["mems"][i].shape:
+                self._graph_state["mems"][i].copy_(new_mems)      # an eager step between replays: the graph's buffers stay current
+                new_mems = self._graph_state["mems"][i]
+            self.mems[i] = new_mems
             loss, nll_sum = masked_mean(loss, t, self.pad_id, 1.0 / chunk, with_sum=True)
             if overlap and i == chunk - 1:
                 # gradients are complete once the LAST micro-batch's backward has passed a layer: exchange that
@@ -119,6 +135,135 @@ class Trainer:
         self.log_grad_norm += grad_norm
         self.log_token_num += int(batch_token_num)
         return total
+
+    # ------------------------------------------------------------------ hipGraph step
+    def _graph_ready(self, data, reset_mems):
+        """Capture / replay only at steady shapes: every micro-batch's XL memory at its full length (or no memory), the
+        optimiser state allocated (one eager step done), and the batch shape of the captured graph."""
+        cfg, model = self.cfg, self.model
+        if self.train_step < 2:
+            return False
+        if cfg.TRAIN.mem_length > 0:
+            for m in self.mems:
+                if m is None or m.shape[1] != cfg.TRAIN.mem_length:
+                    return False
+        key = (tuple(data.shape), data.device, cfg.TRAIN.batch_chunk, bool(model.training), float(model.drop.p))
+        if self._graphs is not None and key != self._graph_key:
+            return False                                      # another shape: eager (the captured graph stays valid)
+        return True
+
+    def _device_forward_backward(self, data, target, reset_mems, mems_in):
+        """The device work of train.py:133-155 without the autograd engine: forward schedule, masked mean, its
+        gradient, backward schedule -- all launches on the current stream (and the model's side streams, joined)."""
+        from . import ops
+        cfg, model = self.cfg, self.model
+        chunk = cfg.TRAIN.batch_chunk
+        model.zero_grad()
+        data_chunks = torch.chunk(data, chunk, 1)
+        target_chunks = torch.chunk(target, chunk, 1)
+        reset_chunks = torch.chunk(reset_mems, chunk, 0)
+        total, nll_sums, mems_out = None, [], []
+        dev = data.device
+        for i in range(chunk):
+            d, t, r = data_chunks[i].contiguous(), target_chunks[i].contiguous(), reset_chunks[i].contiguous()
+            m_in = mems_in[i]
+            if m_in is None:
+                m_in = model.init_mems(model.n_layer)
+            nll, new_mems, sv = model._run_forward(d, t, r, m_in, need_grad=True)
+            ws_sum = torch.empty(1, device=dev, dtype=torch.float32)
+            ws_cnt = torch.empty(1, device=dev, dtype=torch.int32)
+            out = torch.empty(1, device=dev, dtype=torch.float32)
+            tt = t.view(-1)
+            ops.masked_mean(nll.view(-1), tt, int(self.pad_id), 1.0 / chunk, ws_sum, ws_cnt, out)
+            g = torch.empty(tt.numel(), device=dev, dtype=torch.float32)
+            ops.loss_grad(tt, int(self.pad_id), ws_cnt, 1.0 / chunk, g)
+            model._run_backward(sv, g.view(nll.shape))
+            total = out[0] if total is None else total + out[0]
+            nll_sums.append(ws_sum)
+            mems_out.append(new_mems if mems_in[i] is not None or cfg.TRAIN.mem_length > 0 else None)
+        return total, nll_sums, mems_out
+
+    def _capture(self, data, target, reset_mems):
+        from . import ops
+        cfg, model = self.cfg, self.model
+        dev = data.device
+        fl = model._ensure_flat()
+        st = {"data": data.clone(), "target": target.clone(), "reset": reset_mems.clone(),
+              "salt": torch.zeros(1, device=dev, dtype=torch.int32),
+              "scal": torch.zeros(4, device=dev, dtype=torch.float32),
+              "mems": [None if m is None else m.detach().clone() for m in self.mems]}
+        cur = torch.cuda.current_stream(dev)
+        if fl.get("shadow_ready") is not None:                # recorded by the last eager optimiser step: join it here,
+            cur.wait_event(fl["shadow_ready"])                # a captured stream must not wait for an outside event
+            fl["shadow_ready"] = None
+        torch.cuda.synchronize(dev)
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()
+        # (thread_local: the batch producer's worker thread keeps issuing copies on its own stream meanwhile)
+        with torch.cuda.graph(g_fb, pool=pool, capture_error_mode="thread_local"):
+            ops.set_seed_salt(st["salt"])
+            total, nll_sums, mems_out = self._device_forward_backward(st["data"], st["target"], st["reset"], st["mems"])
+            for dst, src in zip(st["mems"], mems_out):
+                if dst is not None:
+                    dst.copy_(src)                            # next replay's memory = this replay's hidden states
+            for s_ in nll_sums:
+                self.log_train_loss += s_[0]
+            ops.set_seed_salt(None)
+        self.optimizer.dev_scalars = st["scal"]
+        try:
+            with torch.cuda.graph(g_opt, pool=pool, capture_error_mode="thread_local"):
+                gn = clip_grad_norm_(model, cfg.TRAIN.clip, self.optimizer)
+                self.optimizer.step()
+                sr = model._flat.get("shadow_ready")
+                if sr is not None:                            # the transposed shadows are built on a side stream: join
+                    torch.cuda.current_stream(dev).wait_event(sr)
+                    model._flat["shadow_ready"] = None
+                self.log_grad_norm += gn
+        finally:
+            self.optimizer.dev_scalars = None
+        st["total"] = total
+        self._graphs, self._graph_state = (g_fb, g_opt), st
+        self._graph_key = (tuple(data.shape), data.device, cfg.TRAIN.batch_chunk, bool(model.training), float(model.drop.p))
+        # the capture itself does not execute anything: the caller replays
+
+    def _graph_step(self, data, target, reset_mems, batch_token_num):
+        """One optimiser step = copy the batch into the graph's input buffers, write the step's dropout salt and the
+        optimiser scalars (lr of the LambdaLR schedule, Adam bias corrections) to device memory, replay.  Host work per
+        step: five small launches + two graph launches, whatever the depth of the model."""
+        from . import ops
+        cfg, model = self.cfg, self.model
+        if self._graphs is None:
+            try:
+                self._capture(data, target, reset_mems)
+            except Exception as exc:                          # capture refused: stay eager (same process, no re-exec)
+                self.graph_failed = f"{type(exc).__name__}: {exc}"
+                self._graphs = None
+                torch.cuda.synchronize()
+                return self.step(data, target, reset_mems, batch_token_num)
+            # hand the live memories to the graph: from now on they live in its static buffers
+            self.mems = self._graph_state["mems"]
+        st = self._graph_state
+        fl = model._flat
+        if fl.get("shadow_ready") is not None:                # an EAGER step ran since the last replay: its transposed
+            torch.cuda.current_stream(data.device).wait_event(fl["shadow_ready"])      # shadows must be complete
+            fl["shadow_ready"] = None
+        st["data"].copy_(data)
+        st["target"].copy_(target)
+        st["reset"].copy_(reset_mems)
+        st["salt"].fill_(int(self.salt_source()))
+        opt = self.optimizer
+        grp = opt.param_groups[0]
+        opt.step_count += 1
+        bc1, bc2 = ops.adam_bias_corrections(grp["betas"][0], grp["betas"][1], opt.step_count)
+        st["scal"].copy_(torch.tensor([float(grp["lr"]), bc1, bc2, 0.0], dtype=torch.float32), non_blocking=True)
+        self._graphs[0].replay()
+        if self.reducer is not None:
+            self.reducer.allreduce_mean(model)
+        self._graphs[1].replay()
+        self.train_step += 1
+        self.scheduler.step()
+        self.log_token_num += int(batch_token_num)
+        return st["total"]
 
     def _sum_over_ranks(self, values):
         """One packed all-reduce for a set of scalars (the reference issues one collective per scalar)."""

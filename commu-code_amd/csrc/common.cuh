@@ -99,5 +99,19 @@ __device__ __forceinline__ unsigned mix32k(unsigned idx, unsigned key) {
 //  only in a few low bits would otherwise change the second round's input by a near-constant)
 __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned idx, unsigned thr) { return mix32k(idx, mix32(seed)) >= thr; }
 
+// Seed salt (one copy per translation unit): every dropout site uses `seed argument + g_seed_salt`.  Eager launches never
+// touch it (0: the seed argument alone decides).  A training step replayed from a hipGraph has its seed ARGUMENTS
+// frozen at capture time, so the step's first nodes (commu_set_seed_salt: one tiny kernel per translation unit) load a
+// fresh salt from device memory and every replay draws new masks, forward and backward of a replay agreeing.
+static __device__ unsigned g_seed_salt = 0u;
+__device__ __forceinline__ unsigned salted(unsigned seed) { return seed + g_seed_salt; }
+static __global__ void set_seed_salt_kernel(const unsigned* __restrict__ src) { g_seed_salt = src ? *src : 0u; }
+#define COMMU_DEFINE_SEED_SALT_SETTER(NAME)                                                     \
+    int NAME(const unsigned* src, hipStream_t stream) {                                         \
+        COMMU_LAUNCH(set_seed_salt_kernel, dim3(1), dim3(1), 0, stream, src);                   \
+        COMMU_LAUNCH_CHECK();                                                                   \
+        return 0;                                                                               \
+    }
+
 __device__ __forceinline__ bf16x8 ld_bf16x8(const bf16* p) { return *(const bf16x8*)p; }
 __device__ __forceinline__ void st_bf16x8(bf16* p, bf16x8 v) { *(bf16x8*)p = v; }

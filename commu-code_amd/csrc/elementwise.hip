@@ -23,7 +23,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
     bf16* dst = out + (size_t)m * ldo;
     const int Dz = min(ldo, (D + 63) & ~63);          // zero-padding contract: columns [D, Dz) are written as 0
     if ((D & 7) == 0 && (ldo & 7) == 0) {          // 8 columns per lane: two 16-byte loads, one 16-byte store
-        const unsigned key = mix32(drop_seed);
+        const unsigned key = mix32(salted(drop_seed));
         for (int c = lane * 8; c < Dz; c += 512) {
             bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
             if (c < D) {
@@ -46,7 +46,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = bad ? __builtin_nanf("") : v[e] * scale;
-            if (drop_thr) x = drop_keep(drop_seed, (unsigned)m * (unsigned)D + (unsigned)(c + e), drop_thr) ? x * drop_scale : 0.f;
+            if (drop_thr) x = drop_keep(salted(drop_seed), (unsigned)m * (unsigned)D + (unsigned)(c + e), drop_thr) ? x * drop_scale : 0.f;
             o[e] = f2bf(x);
         }
         *(bf16x4*)(dst + c) = o;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
                 const int c = tid + 256 * k;
                 if (c < D) {
                     float x = bf2f(row[c]);
-                    if (drop_thr) x = drop_keep(drop_seed, (unsigned)m * (unsigned)D + (unsigned)c, drop_thr) ? x * drop_scale : 0.f;
+                    if (drop_thr) x = drop_keep(salted(drop_seed), (unsigned)m * (unsigned)D + (unsigned)c, drop_thr) ? x * drop_scale : 0.f;
                     acc[k] += x;
                 }
             }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(
     const int v = blockIdx.x, sp = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long b0 = offs[v], b1 = offs[v + 1];
     const long long per = (b1 - b0 + S - 1) / S, lo = b0 + sp * per, hi = min(b1, lo + per);
-    const unsigned key = mix32(drop_seed);
+    const unsigned key = mix32(salted(drop_seed));
     float acc[NC][8];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -165,8 +165,8 @@ __global__ void posemb_kernel(const float* __restrict__ inv_freq, bf16* __restri
     const float ang = (float)d * inv_freq[i];
     float sv = sinf(ang), cv = cosf(ang);
     if (drop_thr) {
-        sv = drop_keep(drop_seed, (unsigned)d * (unsigned)D + (unsigned)i, drop_thr) ? sv * drop_scale : 0.f;
-        cv = drop_keep(drop_seed, (unsigned)d * (unsigned)D + (unsigned)(half + i), drop_thr) ? cv * drop_scale : 0.f;
+        sv = drop_keep(salted(drop_seed), (unsigned)d * (unsigned)D + (unsigned)i, drop_thr) ? sv * drop_scale : 0.f;
+        cv = drop_keep(salted(drop_seed), (unsigned)d * (unsigned)D + (unsigned)(half + i), drop_thr) ? cv * drop_scale : 0.f;
     }
     out[(size_t)d * ld + i] = f2bf(sv);
     out[(size_t)d * ld + half + i] = f2bf(cv);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
                 bf16x8 od;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    od[e] = f2bf(((e < 4 || hi) && drop_keep(drop_seed, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr))
+                    od[e] = f2bf(((e < 4 || hi) && drop_keep(salted(drop_seed), (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr))
                                      ? x[c][e] * drop_scale : 0.f);
                 st_bf16x8(ydrop + (size_t)row * ldyd + col, od);
             } else if (col < min(ldyd, (D + 63) & ~63)) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const int r0 = blockIdx.x * LNB_ROWS + w * LNB_WROWS;
     const int nr = min(LNB_WROWS, rows - r0);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned key = mix32(drop_seed);
+    const unsigned key = mix32(salted(drop_seed));
     const float invD = 1.f / (float)D;
     bf16x8 vz[2][NC], vd[2][NC], nz[2][NC], nd[2][NC];
     float vmu[2], vrs[2], nmu[2], nrs[2];
@@ -640,6 +640,32 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// the same step with lr and the two bias corrections read from DEVICE memory (scal = {lr, 1 - b1^t, 1 - b2^t}): what a
+// hipGraph-captured optimiser step replays -- the host refreshes the three floats before every replay
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       bf16* __restrict__ pb, size_t n, const float* __restrict__ scal,
+                                                       float b1, float b2, float eps,
+                                                       const float* __restrict__ gnorm, float clip) {
+    float coef = 1.f;
+    if (gnorm != nullptr && clip > 0.f) coef = fminf(1.f, clip / (gnorm[0] + 1e-6f));
+    const float lr = scal[0], bc1 = scal[1], bc2 = scal[2];
+    const float step = lr / bc1, isb2 = 1.f / sqrtf(bc2);
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        const int cnt = (i + 3 < n) ? 4 : (int)(n - i);
+        for (int e = 0; e < cnt; ++e) {
+            const float gr = g[i + e] * coef;
+            const float mm = b1 * m[i + e] + (1.f - b1) * gr;
+            const float vv = b2 * v[i + e] + (1.f - b2) * gr * gr;
+            m[i + e] = mm;
+            v[i + e] = vv;
+            const float np = p[i + e] - step * mm / (sqrtf(vv) * isb2 + eps);
+            p[i + e] = np;
+            if (pb) pb[i + e] = f2bf(np);
+        }
+    }
+}
+
 __global__ void scale_clip_kernel(float* __restrict__ g, size_t n, const float* __restrict__ gnorm, float clip) {
     const float coef = fminf(1.f, clip / (gnorm[0] + 1e-6f));
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -902,6 +928,27 @@ extern "C" int commu_adam_step(float* p, const float* g, float* m, float* v, voi
     COMMU_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int commu_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n,
+                                   const float* scal, float beta1, float beta2, float eps, const float* gnorm,
+                                   float clip, hipStream_t stream) {
+    if (n == 0) return 0;
+    if (scal == nullptr) return -22;
+    COMMU_LAUNCH(adam_dev_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
+                 (bf16*)p_bf16, n, scal, beta1, beta2, eps, gnorm, clip);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+/* bias corrections exactly as commu_adam_step computes them (so that a host can fill the device scalars of
+ * commu_adam_step_dev with bit-identical values) */
+extern "C" int commu_adam_bias_corrections(float beta1, float beta2, int step, float* out2) {
+    out2[0] = 1.f - powf(beta1, (float)step);
+    out2[1] = 1.f - powf(beta2, (float)step);
+    return 0;
+}
+
+COMMU_DEFINE_SEED_SALT_SETTER(commu_seed_salt_elementwise)
 
 extern "C" int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, float clip, hipStream_t stream) {
     if (n == 0) return 0;

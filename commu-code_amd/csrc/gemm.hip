@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
             if (flags & COMMU_EPI_DROPOUT) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    v[e] = drop_keep(drop_seed, (unsigned)m * (unsigned)N + (unsigned)(n + e), drop_thr) ? v[e] * drop_scale : 0.f;
+                    v[e] = drop_keep(salted(drop_seed), (unsigned)m * (unsigned)N + (unsigned)(n + e), drop_thr) ? v[e] * drop_scale : 0.f;
             }
             if (flags & COMMU_EPI_RESID) {
                 const bf16* rp = resid + (size_t)m * ldr + n;
@@ -994,3 +994,5 @@ extern "C" int commu_gemm_nt_ln_bf16(const void* z, int ldz, const float* gamma,
     return launch_gemm_nt(z, ldz, B, ldb, C, ldc, M, N, K, bias, resid, ldr, nullptr, 0, flags, 0u, 0.f, 1.f, 1,
                           GemmBatch{0, 0, 0, 0, 0, 0}, stream, &ln);
 }
+
+COMMU_DEFINE_SEED_SALT_SETTER(commu_seed_salt_gemm)

@@ -76,7 +76,7 @@ __device__ __forceinline__ void g8_store_one(const G8Args& a, float v, int m, in
     if (flags & COMMU_EPI_BIAS) v += a.bias[n];
     if (flags & COMMU_EPI_RELU) v = fmaxf(v, 0.f);
     if (flags & COMMU_EPI_DROPOUT)
-        v = drop_keep(a.drop_seed, (unsigned)m * (unsigned)a.N + (unsigned)n, a.drop_thr) ? v * a.drop_scale : 0.f;
+        v = drop_keep(salted(a.drop_seed), (unsigned)m * (unsigned)a.N + (unsigned)n, a.drop_thr) ? v * a.drop_scale : 0.f;
     if (flags & COMMU_EPI_RESID) v += bf2f(a.resid[(size_t)m * a.ldr + n]);
     if (flags & COMMU_EPI_RELUMASK) v = (bf2f(a.rmask[(size_t)m * a.ldm + n]) > 0.f) ? v * a.mask_scale : 0.f;
     if (OUT_F32) ((float*)a.C)[(size_t)m * a.ldc + n] = v;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void g8_store(const G8Args& a, f32x4 (&acc)[4][8], in
                 if (flags & COMMU_EPI_DROPOUT) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        v[e] = drop_keep(a.drop_seed, (unsigned)m * (unsigned)N + (unsigned)(n + e), a.drop_thr)
+                        v[e] = drop_keep(salted(a.drop_seed), (unsigned)m * (unsigned)N + (unsigned)(n + e), a.drop_thr)
                                    ? v[e] * a.drop_scale : 0.f;
                 }
                 if (flags & COMMU_EPI_RESID) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (flags & COMMU_EPI_DROPOUT) {
-            const unsigned key = mix32(a.drop_seed), i0 = (unsigned)m * (unsigned)N + (unsigned)n;
+            const unsigned key = mix32(salted(a.drop_seed)), i0 = (unsigned)m * (unsigned)N + (unsigned)n;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = mix32k(i0 + (unsigned)e, key) >= a.drop_thr ? v[e] * a.drop_scale : 0.f;
         }
@@ -830,3 +830,5 @@ int launch_gemm8_tn(const Tn8Args& a, hipStream_t stream) {
     COMMU_LAUNCH_CHECK();
     return 0;
 }
+
+COMMU_DEFINE_SEED_SALT_SETTER(commu_seed_salt_gemm8)

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_nt_mxfp8_kernel(const F8Args a) {
                 float x = acc[i][j][reg] + bv;
                 if (a.flags & COMMU_EPI_RELU) x = fmaxf(x, 0.f);
                 if (a.flags & COMMU_EPI_DROPOUT)
-                    x = drop_keep(a.drop_seed, (unsigned)row * (unsigned)a.N + (unsigned)col, a.drop_thr) ? x * a.drop_scale : 0.f;
+                    x = drop_keep(salted(a.drop_seed), (unsigned)row * (unsigned)a.N + (unsigned)col, a.drop_thr) ? x * a.drop_scale : 0.f;
                 if ((a.flags & COMMU_EPI_RESID) && row < a.M && col < a.N) x += bf2f(a.resid[(size_t)row * a.ldr + col]);
                 ep[(16 * i + 4 * g + reg) * 72 + 16 * j + r16] = f2bf(x);
             }
@@ -238,3 +238,5 @@ extern "C" int commu_gemm_nt_mxfp8(const void* A, int lda, const void* SA, int l
     COMMU_LAUNCH_CHECK();
     return 0;
 }
+
+COMMU_DEFINE_SEED_SALT_SETTER(commu_seed_salt_gemm_fp8)

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     DropLane dl_;
-    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
     const unsigned thr_hi = a.drop_thr << 16;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;           // bytes between consecutive kv rows
     const float c2 = a.scale * LOG2E;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     tile_coords(QH, a.H, B, qslot, h, b);
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     DropLane dl_;
-    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
     const unsigned thr_hi = a.drop_thr << 16;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u, rdb = (unsigned)a.ld_rd * 2u;
     const float c2 = a.scale * LOG2E;
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     DropLane dl_;
-    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
     const unsigned thr_hi = a.drop_thr << 16;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;
     const int HD = a.H * DH;
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
     const int j0 = jt * KCOLS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     DropLane dl_;
-    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
     const unsigned thr_hi = a.drop_thr << 16;
     const int HD = a.H * DH;
     // With P' = P ln2/(1-p) (the factor goes into the exponent through sLse):  dS'' = P' (keep dP - delta (1-p))  and
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     tile_coords(NH, a.H, B, jslot, h, b);
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     DropLane dl_;
-    if (DROP) dl_.init(a.drop_seed, b, h, a.H, g, r16);
+    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
     const unsigned thr_hi = a.drop_thr << 16;
     // P' = P ln2/(1-p):  dS'' = P' (keep dP - delta (1-p)),  dV = [sum keep P' dO] / ln2   (see relattn_bwd_kv_kernel);
     // stored is P scale/(1-p)
@@ -1536,6 +1536,8 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16* __rest
 }
 
 }  // namespace
+
+COMMU_DEFINE_SEED_SALT_SETTER(commu_seed_salt_relattn)
 
 static void fill_common(AttnArgs& a, const commu_attn_desc* d) {
     a.u = d->r_w_bias; a.vb = d->r_r_bias; a.reset = d->reset;

@@ -186,6 +186,16 @@ int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out
 int commu_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, float lr,
                     float beta1, float beta2, float eps, int step, const float* gnorm, float clip,
                     hipStream_t stream);
+/* The same step with {lr, 1 - beta1^t, 1 - beta2^t} read from DEVICE memory (`scal`, three floats): the form a
+ * hipGraph-captured training step replays; commu_adam_bias_corrections (host-only, no stream) gives the two
+ * corrections exactly as commu_adam_step computes them. */
+int commu_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, const float* scal,
+                        float beta1, float beta2, float eps, const float* gnorm, float clip, hipStream_t stream);
+int commu_adam_bias_corrections(float beta1, float beta2, int step, float* out2);
+/* Dropout seed salt: every dropout site of every kernel uses (its seed argument + salt); the salt is 0 until this call
+ * loads it from device memory (src == NULL: back to 0).  Kernel arguments of a captured hipGraph are frozen, the salt
+ * is not: a captured training step starts with this call and draws fresh masks on every replay. */
+int commu_set_seed_salt(const unsigned* src, hipStream_t stream);
 /* g *= min(1, clip / (gnorm[0] + 1e-6)) */
 int commu_scale_clip_f32(float* g, size_t n, const float* gnorm, float clip, hipStream_t stream);
 int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t stream);
@@ -337,6 +347,13 @@ int commu_copy_rows_masked_f32(float* dst, int ldd, const float* src, int lds, c
 
 /* library identification */
 const char* commu_hip_version(void);
+
+/* Host-side (no GPU): assemble one [T][B] int64 training batch from the flat corpus.  Column c streams sequence
+ * seq[c] (-1: none) from position pos[c]: data[r][c] = tokens[offsets[seq[c]] + pos[c] + r] for r < cnt[c], target the
+ * same shifted by one, `pad` elsewhere (commu/model/dataset.py:139-170).  Returns the number of non-pad targets
+ * (sum of cnt), -22 for B > 1024.  Thread-safe; called without the GIL by the prefetch thread. */
+long long commu_pack_batch(const int64_t* tokens, const int64_t* offsets, const int64_t* seq, const int64_t* pos,
+                           const int64_t* cnt, int B, int T, int64_t pad, int64_t* data, int64_t* target);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,8 @@ f=$(find $out -name "*kernel_stats.csv" | head -1)
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 print("# calls total_us avg_us pct name")
+tot = sum(float(r['TotalDurationNs']) for r in rows) / 1e3
+print(f"# sum of all kernel durations: {tot:.1f} us over the whole run ({len(rows)} kernels)")
 for r in rows[:32]:
     print(f"{int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e3:12.1f} {float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}  {r['Name'][:120]}")
 PY

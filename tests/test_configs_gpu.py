@@ -259,3 +259,63 @@ def test_grouped_weight_gradients_match_the_per_gemm_path(mem_len, T, B, monkeyp
             scale = float(ref[n].abs().max()) + 1e-12
             err = float((got[n] - ref[n]).abs().max()) / scale
             assert err < 2e-3, (mem_len, rep, n, err)
+
+
+@pytest.mark.parametrize("variant", ["nomem_chunk1", "mem_chunk2", "padded_dh50"])
+def test_graph_step_matches_eager_step(variant):
+    """Trainer(graph=True): the optimiser step replayed from two hipGraphs (forward + backward of every micro-batch;
+    clip + Adam + weight shadows) against the eager step, same seeds: dropout ON with the same base seeds and the same
+    per-step salt written to device memory (eager kernels read the salt too), LR schedule through the device scalars.
+    Parameters after 6 steps agree to fp32 summation-order noise (bias / LayerNorm column sums end in atomics), the
+    losses of every step likewise, and the XL memory is carried through the graph's static buffers."""
+    from commu_amd import ops
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import Trainer, build_model
+    dev = torch.device(DEV)
+    if variant == "nomem_chunk1":
+        kw = dict(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=128, mem_length=0, batch_size=8, batch_chunk=1)
+    elif variant == "mem_chunk2":
+        kw = dict(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=64, mem_length=64, batch_size=8, batch_chunk=2)
+    else:
+        kw = dict(num_layers=2, num_heads=2, units=100, inner_size=200, tgt_length=64, mem_length=64, batch_size=4, batch_chunk=1)
+    cfg = get_cfg(dropout=0.1, attention_dropout=0.1, **kw)
+    T, B = kw["tgt_length"], kw["batch_size"]
+    batches = [synthetic_batch(T, B, dev, seed=50 + i, reset_prob=0.2 if kw["mem_length"] else 0.0) for i in range(6)]
+    salts = [1234567 + 977 * i for i in range(6)]
+    out = {}
+    for mode in ("eager", "graph"):
+        model = build_model(cfg, BaseVocab(), dev, seed=3)
+        model.train()
+        model.fixed_drop_seed = 4242          # same base seeds in both runs; the per-step salt makes the masks differ by step
+        tr = Trainer(model, cfg, num_gpus=1, graph=(mode == "graph"))
+        salt = torch.zeros(1, device=dev, dtype=torch.int32)
+        losses, replayed = [], 0
+        for i, b in enumerate(batches):
+            if tr.graph_mode and tr._graph_ready(b[0], b[2]):
+                tr.salt_source = lambda i=i: salts[i]          # written to device memory by _graph_step
+                losses.append(float(tr.step(*b)))
+                replayed += 1
+            else:
+                salt.fill_(salts[i])
+                ops.set_seed_salt(salt)                        # eager kernels read the salt as well
+                try:
+                    losses.append(float(tr.step(*b)))
+                finally:
+                    ops.set_seed_salt(None)
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert tr.graph_failed is None, tr.graph_failed
+            assert tr._graphs is not None and replayed >= 2
+        out[mode] = (losses, {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()},
+                     [None if m is None else m.float().cpu().clone() for m in tr.mems], tr.log_window())
+    le, lg = out["eager"][0], out["graph"][0]
+    assert all(abs(a - b) < 2e-4 for a, b in zip(le, lg)), (le, lg)
+    for n in out["eager"][1]:
+        a, b = out["eager"][1][n], out["graph"][1][n]
+        assert float((a - b).abs().max()) <= 2e-5 + 2e-3 * float(a.abs().max()), (n, float((a - b).abs().max()))
+    for a, b in zip(out["eager"][2], out["graph"][2]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
+    assert abs(out["eager"][3][0] - out["graph"][3][0]) < 1e-4 and out["eager"][3][2] == out["graph"][3][2]
