@@ -401,11 +401,14 @@ def layernorm_bwd_reduce(part, dgamma, dbeta, dbias=None):
     call("commu_layernorm_bwd_reduce", _p(part), nblk, D, _p(dgamma), _p(dbeta), _p(dbias), _s())
 
 
-def colsum(X, out):
-    """out[c] += sum_r X[r, c]  (X bf16 or fp32)."""
+def colsum(X, out, alpha=1.0):
+    """out[c] += alpha * sum_r X[r, c]  (X bf16 or fp32; deterministic two-pass sum, no atomics)."""
     rows, cols = X.shape
-    name = "commu_colsum_bf16" if X.dtype == BF16 else "commu_colsum_f32"
-    call(name, _p(X), X.stride(0), rows, cols, _p(out), _s())
+    bf = X.dtype == BF16
+    ny = call("commu_colsum_slabs", rows, cols, 2 if bf else 4)
+    ws = torch.empty(ny, round_up(cols, 8), device=X.device, dtype=F32) if ny > 0 else None
+    call("commu_colsum_bf16" if bf else "commu_colsum_f32", _p(X), X.stride(0), rows, cols, _p(out), _p(ws), ny,
+         float(alpha), _s())
     return out
 
 
@@ -686,16 +689,14 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
 
 
 def _bias_grads(dq, du_part, du, dvb, HD, dev, defer):
-    """d r_w_bias = colsum(dq_ac) ; d r_r_bias = colsum(dq) - colsum(dq_ac)   (gradients only: deferrable)"""
+    """d r_w_bias += colsum(dq_ac) ; d r_r_bias += colsum(dq) - colsum(dq_ac)   (gradients only: deferrable).
+    du_part holds the per-query-tile column sums of dq_ac; three column-sum launches, no temporaries."""
     def bias_part():
         if defer is not None:          # local scratch outlives the caller on the deferring stream
             du_part.record_stream(torch.cuda.current_stream())
-        ca = torch.zeros(HD, device=dev, dtype=F32)
-        colsum(du_part, ca)
-        ct = torch.zeros(HD, device=dev, dtype=F32)
-        colsum(dq, ct)
-        du.add_(ca)
-        dvb.add_(ct - ca)
+        colsum(du_part, du)
+        colsum(dq, dvb)
+        colsum(du_part, dvb, alpha=-1.0)
     if defer is None:
         bias_part()
     else:

@@ -384,96 +384,104 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     }
 }
 
-// out[c] += sum_r X[r, c]   (atomics: one per block per column; out pre-zeroed or a grad to add into)
+// Column sums  out[c] += sum_r X[r, c]  WITHOUT atomics (fp32 atomics on ~100 contended addresses made these the slowest
+// bandwidth kernels of the step: 65-110 us for 2-130 MB; and the result depended on the arrival order).  Two passes:
+//   pass 1: workgroup (bx, by) sums row slab by of a 512-column (bf16, 16-byte loads) / 256-column (fp32) strip and
+//           STORES its partial row to ws[by][c];
+//   pass 2: out[c] += sum over the slabs, in slab order (deterministic).
+// Small inputs (LayerNorm partials, per-tile bias sums: a few MB) take pass 2 alone on the input itself.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, int rows,
-                                                     int cols, float* __restrict__ out,
-                                                     int rows_per_block) {
-    __shared__ float red[4][256];
+__global__ __launch_bounds__(256) void colsum_slab_kernel(const T* __restrict__ X, int ldx, int rows, int cols,
+                                                          float* __restrict__ ws, int rows_per_block) {
+    constexpr int V = sizeof(T) == 2 ? 8 : 4;          // elements per 16-byte load
+    __shared__ float red[4][64 * V];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * 256 + lane * 4;
-    const int rbeg = blockIdx.y * rows_per_block;
-    const int rend = min(rows, rbeg + rows_per_block);
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c0 < cols) {
-        for (int r = rbeg + w; r < rend; r += 4) {
-            const T* p = X + (size_t)r * ldx + c0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c0 + e < cols) a[e] += (float)p[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
-    __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < cols) {
-        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(out + c, s);
-    }
-}
-
-// the three partial-sum planes of layernorm_bwd ([nblk][3][D]) reduced by ONE launch: plane z -> out{z}
-__global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ part, int rows, int D,
-                                                      float* __restrict__ o0, float* __restrict__ o1,
-                                                      float* __restrict__ o2, int rows_per_block) {
-    __shared__ float red[4][256];
-    const int z = blockIdx.z;
-    float* out = z == 0 ? o0 : (z == 1 ? o1 : o2);
-    if (out == nullptr) return;
-    const float* X = part + (size_t)z * D;
-    const int ldx = 3 * D;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * 256 + lane * 4;
+    const int c0 = blockIdx.x * 64 * V + lane * V;
     const int rbeg = blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c0 < D) {
-        for (int r = rbeg + w; r < rend; r += 4) {
-            const float* p = X + (size_t)r * ldx + c0;
+    float a[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c0 + e < D) a[e] += p[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[w][lane * 4 + e] = a[e];
-    __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < D) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
-
-// bf16 fast path: 16-byte loads (8 columns per lane, 512 per workgroup), 4 rows in flight per wave
-__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16* __restrict__ X, int ldx, int rows, int cols,
-                                                            float* __restrict__ out, int rows_per_block) {
-    __shared__ float red[4][512];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * 512 + lane * 8;
-    const int rbeg = blockIdx.y * rows_per_block;
-    const int rend = min(rows, rbeg + rows_per_block);
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (c0 < cols) {          // (cols % 8 == 0: whole chunks)
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    if (c0 < cols) {          // (cols rounded up to V by the caller: whole 16-byte chunks inside the row pitch)
         int r = rbeg + w;
-        for (; r + 12 < rend; r += 16) {
-            bf16x8 v[4];
+        for (; r + 12 < rend; r += 16) {          // four rows in flight per wave
+            f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ld_bf16x8(X + (size_t)(r + 4 * u) * ldx + c0);
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(X + (size_t)(r + 4 * u) * ldx + c0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (V == 8) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, v[u]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] += bf2f(v[u][e]);
+                    for (int e = 0; e < 8; ++e) a[e] += bf2f(b[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] += v[u][e];
+                }
+            }
         }
         for (; r < rend; r += 4) {
-            const bf16x8 v = ld_bf16x8(X + (size_t)r * ldx + c0);
+            const f32x4 v = *(const f32x4*)(X + (size_t)r * ldx + c0);
+            if constexpr (V == 8) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += bf2f(v[e]);
+                for (int e = 0; e < 8; ++e) a[e] += bf2f(b[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] += v[e];
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = a[e];
+    for (int e = 0; e < V; ++e) red[w][lane * V + e] = a[e];
     __syncthreads();
-    for (int t = threadIdx.x; t < 512; t += 256) {
-        const int c = blockIdx.x * 512 + t;
-        if (c < cols) atomicAdd(out + c, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+    for (int t = threadIdx.x; t < 64 * V; t += 256) {
+        const int c = blockIdx.x * 64 * V + t;
+        if (c < cols) ws[(size_t)blockIdx.y * cols + c] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    }
+}
+
+// out[c] += sum_{r < rows} X[r * ldx + c] for fp32 X, rows in order; up to three planes (blockIdx.y: X + z * plane,
+// out = o0 / o1 / o2, a null output is skipped).  One workgroup per 64 columns: 16 row lanes x 16 float4 column lanes.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ X, int ldx, size_t plane, int rows,
+                                                           int cols, float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ o2, float alpha) {
+    __shared__ f32x4 red[16][16];
+    const int z = blockIdx.y;
+    float* out = z == 0 ? o0 : (z == 1 ? o1 : o2);
+    if (out == nullptr) return;
+    const float* P = X + (size_t)z * plane;
+    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c0 = blockIdx.x * 64 + cl * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {
+        const bool vec = c0 + 3 < cols && ((ldx & 3) == 0) && ((((size_t)P) & 15) == 0);
+        int r = rl;
+        if (vec) {
+            for (; r + 48 < rows; r += 64) {          // four loads in flight
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(P + (size_t)(r + 16 * u) * ldx + c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += v[u];
+            }
+            for (; r < rows; r += 16) a += *(const f32x4*)(P + (size_t)r * ldx + c0);
+        } else {
+            for (; r < rows; r += 16)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < cols) a[e] += P[(size_t)r * ldx + c0 + e];
+        }
+    }
+    red[rl][cl] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < cols) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x >> 2][threadIdx.x & 3];
+            out[c] += alpha * s;
+        }
     }
 }
 
@@ -839,48 +847,59 @@ extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int 
     return 0;
 }
 
-extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream) {
+/* rows of the fp32 workspace (`cols` rounded up to 8 floats each) the column sum of a rows x cols input needs;
+ * 0: none (a small fp32 input is summed by the final pass alone) */
+extern "C" int commu_colsum_slabs(int rows, int cols, int elem_bytes) {
     if (rows <= 0 || cols <= 0) return 0;
-    if ((cols % 8) == 0 && (ldx % 8) == 0) {
-        const int nx = (cols + 511) / 512;
-        int ny = (rows + 63) / 64;
-        const int cap = (512 + nx - 1) / nx;           // ~512 workgroups: enough loads in flight, few same-address atomics
-        if (ny > cap) ny = cap;
-        const int rpb = (rows + ny - 1) / ny;
-        COMMU_LAUNCH(colsum_bf16x8_kernel, dim3(nx, ny), dim3(256), 0, stream, (const bf16*)X, ldx, rows, cols, out, rpb);
+    const bool small = (size_t)rows * cols * elem_bytes <= ((size_t)4 << 20);
+    if (small && elem_bytes == 4) return 0;
+    const int strip = elem_bytes == 2 ? 512 : 256;
+    const int nx = (cols + strip - 1) / strip;
+    const int ny = (rows + 63) / 64;
+    const int cap = small ? 256 : (1024 + nx - 1) / nx;          // ~1024 workgroups on a large input
+    return ny > cap ? cap : ny;
+}
+
+template <typename T>
+static int colsum_launch(const T* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows, float alpha,
+                         hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    constexpr int V = sizeof(T) == 2 ? 8 : 4;
+    const int ny = commu_colsum_slabs(rows, cols, (int)sizeof(T));
+    if (ny == 0) {          // small fp32 input
+        COMMU_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, (const float*)X, ldx, (size_t)0,
+                     rows, cols, out, (float*)nullptr, (float*)nullptr, alpha);
         COMMU_LAUNCH_CHECK();
         return 0;
     }
-    int ny = (rows + 255) / 256;
-    if (ny > 256) ny = 256;
-    const int rpb = (rows + ny - 1) / ny;
-    COMMU_LAUNCH(colsum_kernel<bf16>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream,
-                       (const bf16*)X, ldx, rows, cols, out, rpb);
+    const int colsv = (cols + V - 1) / V * V;          // whole 16-byte chunks (pad columns are summed and ignored)
+    if (ws == nullptr || ws_rows < ny || colsv > ldx || (ldx % V) || (((size_t)X) & 15)) return -22;
+    COMMU_LAUNCH((colsum_slab_kernel<T>), dim3((colsv + 64 * V - 1) / (64 * V), ny), dim3(256), 0, stream, X, ldx, rows,
+                 colsv, ws, (rows + ny - 1) / ny);
+    COMMU_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, ws, colsv, (size_t)0, ny, cols, out,
+                 (float*)nullptr, (float*)nullptr, alpha);
     COMMU_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows,
+                                 float alpha, hipStream_t stream) {
+    return colsum_launch<bf16>((const bf16*)X, ldx, rows, cols, out, ws, ws_rows, alpha, stream);
 }
 
 extern "C" int commu_layernorm_bwd_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta,
                                           float* dbias, hipStream_t stream) {
     if (nblk <= 0 || D <= 0) return 0;
-    int ny = (nblk + 63) / 64;
-    if (ny > 64) ny = 64;
-    const int rpb = (nblk + ny - 1) / ny;
-    COMMU_LAUNCH(colsum3_kernel, dim3((D + 255) / 256, ny, 3), dim3(256), 0, stream, part, nblk, D, dgamma, dbeta, dbias,
-                 rpb);
+    // part is [nblk][3][D]: plane z of row r at part + (3 r + z) D  ->  row pitch 3 D, plane offset D
+    COMMU_LAUNCH(colsum_final_kernel, dim3((D + 63) / 64, 3), dim3(256), 0, stream, part, 3 * D, (size_t)D, nblk, D,
+                 dgamma, dbeta, dbias, 1.f);
     COMMU_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, hipStream_t stream) {
-    if (rows <= 0 || cols <= 0) return 0;
-    int ny = (rows + 63) / 64;
-    if (ny > 256) ny = 256;
-    const int rpb = (rows + ny - 1) / ny;
-    COMMU_LAUNCH(colsum_kernel<float>, dim3((cols + 255) / 256, ny), dim3(256), 0, stream, X, ldx,
-                       rows, cols, out, rpb);
-    COMMU_LAUNCH_CHECK();
-    return 0;
+extern "C" int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows,
+                                float alpha, hipStream_t stream) {
+    return colsum_launch<float>(X, ldx, rows, cols, out, ws, ws_rows, alpha, stream);
 }
 
 extern "C" int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse,

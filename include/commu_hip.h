@@ -165,9 +165,15 @@ int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const 
 /* dgamma += sum_blocks part[:,0,:], dbeta += part[:,1,:], dbias += part[:,2,:] (each destination optional) */
 int commu_layernorm_bwd_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta, float* dbias,
                                hipStream_t stream);
-/* out[c] += sum_r X[r,c]   (bias gradients) */
-int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
-int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, hipStream_t stream);
+/* out[c] += alpha * sum_r X[r,c]   (bias gradients).  No atomics, fixed summation order: row slabs are summed into the fp32
+ * workspace `ws` (commu_colsum_slabs(rows, cols, element bytes) rows of round_up(cols, 8) floats; 0 rows: not needed),
+ * then over the slabs.  Rows must be 16-byte aligned chunks (ldx % 8 == 0 for bf16, % 4 for fp32, round_up(cols) <= ldx);
+ * -22 otherwise or when the workspace is missing. */
+int commu_colsum_slabs(int rows, int cols, int elem_bytes);
+int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows, float alpha,
+                      hipStream_t stream);
+int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows, float alpha,
+                     hipStream_t stream);
 
 /* ---- output layer loss (ProjectedAdaptiveLogSoftmax.forward, n_clusters == 0: model.py:64-73) */
 int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse, int rows,

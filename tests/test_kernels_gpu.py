@@ -450,6 +450,19 @@ def test_colsum():
     out = torch.zeros(40, device=DEV)
     o.colsum(Xf.to(DEV), out)
     assert relerr(out, Xf.sum(0)) < 1e-5
+    # the shapes of the training step: a [rows, 729] view of 768-wide rows (pad columns hold garbage), large inputs
+    # (two passes over a workspace), fp32 per-tile partials, odd column counts; and the sum is DETERMINISTIC (no atomics)
+    big = bf(rnd(9000, 768, seed=21))
+    big[:, 729:] = 1e4
+    for X, cols in ((big.to(DEV)[:, :729], 729), (bf(rnd(70000, 1024, seed=22)).to(DEV), 1024),
+                    (rnd(1024, 512, seed=23).to(DEV), 512), (rnd(5000, 500, seed=24).to(DEV), 500),
+                    (rnd(3001, 203 * 4, seed=25).to(DEV)[:, :810], 810)):
+        a, b = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+        o.colsum(X, a)
+        o.colsum(X, b)
+        assert torch.equal(a, b)
+        ref = X.double().sum(0).float()
+        assert relerr(a, ref) < (2e-3 if X.dtype == torch.bfloat16 else 1e-5), (cols, relerr(a, ref))
 
 
 def test_ce_fwd_bwd():
