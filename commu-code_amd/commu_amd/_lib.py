@@ -61,7 +61,8 @@ PROTOTYPES = {
     "commu_reduce_slabs_crop_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_z, c_i, c_f, c_p],
     "commu_embed_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, C.c_uint, c_f, c_p],
     "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, C.c_uint, c_f, c_p],
-    "commu_embed_bwd_sorted": [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
+    "commu_embed_bwd_ws_rows": [c_i, c_i],
+    "commu_embed_bwd_sorted": [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_f, c_i, C.c_uint, c_f, c_p],
     "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_bwd_nblocks": [c_i],
@@ -109,7 +110,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
             "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
             "commu_forcing_state_ints", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
 
 _lib = None

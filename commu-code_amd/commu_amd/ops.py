@@ -342,19 +342,17 @@ def token_order(tok, V):
     return perm, offs
 
 
-EMBED_SPLITS = 4          # slabs per vocabulary row (bounds the longest list one workgroup walks when a few ids dominate)
-
-
 def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0, order=None):
     """dE[v] (+)= sqrt(D) * sum over the tokens with id v of the (dropout-masked) dX rows.  order = token_order(tok, V):
-    the sorted kernel (no scan of the token list per row, fixed summation order); None: one workgroup per row scans."""
+    the sorted two-pass kernel (work per wave independent of how often an id occurs, fixed summation order); None: one
+    workgroup per row scans the token list."""
     V, D = dE.shape
     if order is not None and dE.is_contiguous():
         perm, offs = order
-        slabs = torch.empty(EMBED_SPLITS, V, D, device=dE.device, dtype=F32)
-        call("commu_embed_bwd_sorted", _p(perm), _p(offs), _p(dX), dX.stride(0), _p(slabs), EMBED_SPLITS, D, V,
-             int(drop_seed), float(drop_p), _s())
-        reduce_slabs(dE, slabs, V * D, EMBED_SPLITS, V * D, accumulate, alpha=math.sqrt(D))
+        ntok = perm.numel()
+        ws = torch.empty(call("commu_embed_bwd_ws_rows", ntok, V), D, device=dE.device, dtype=F32)
+        call("commu_embed_bwd_sorted", _p(perm), _p(offs), _p(dX), dX.stride(0), _p(ws), ntok, D, V, _p(dE), math.sqrt(D),
+             1 if accumulate else 0, int(drop_seed), float(drop_p), _s())
         return dE
     call("commu_embed_bwd", _p(tok), _p(dX), dX.stride(0), _p(dE), tok.numel(), D, V, math.sqrt(D),
          1 if accumulate else 0, int(drop_seed), float(drop_p), _s())

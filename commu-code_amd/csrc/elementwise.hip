@@ -102,56 +102,142 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 // the gradient.  No scan of the token list (the kernel above reads it once per vocabulary row: 382 MB at V = 729), no
 // atomics (fp32 LDS atomics cost ~170 cycles per wave instruction here: a table-in-LDS version took 185 us), and the
 // order of the additions is fixed.
+// Load-balanced form (what runs): a vocabulary row that dominates the batch -- the pad / start id 0 is a quarter of
+// the tokens of a real batch -- made "one workgroup per (row, split)" walk thousands of rows in sequence (0.64 ms against
+// 0.03 ms on uniform ids).  Two passes over the SORTED token list instead:
+//   pass 1: every WAVE takes EMB_CHUNK consecutive sorted tokens and adds their dX rows run by run (a run = equal ids);
+//           the sum of the run of id v in chunk c goes to partial row v + c (both grow along the list, so v + c is
+//           unique; at most V + nchunks rows);
+//   pass 2: row v of dE (+)= scale * sum of its partial rows v + c, c = first .. last chunk that holds a token of v.
+// Work per wave is bounded by the chunk, the summation order is fixed, no atomics.
+constexpr int EMB_CHUNK = 32;
 template <int NC>          // NC 8-element chunks per lane: D <= 512 * NC
-__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(
+__global__ __launch_bounds__(256) void embed_bwd_runs_kernel(
     const int64_t* __restrict__ perm, const int64_t* __restrict__ offs, const bf16* __restrict__ dX, int ldx,
-    float* __restrict__ slabs, int D, int V, int S, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
-    __shared__ float red[4][512 * NC];
-    const int v = blockIdx.x, sp = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long b0 = offs[v], b1 = offs[v + 1];
-    const long long per = (b1 - b0 + S - 1) / S, lo = b0 + sp * per, hi = min(b1, lo + per);
+    float* __restrict__ part, int ntok, int D, int V, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);          // this wave's chunk
+    const long long lo = (long long)c * EMB_CHUNK, hi = min((long long)ntok, lo + EMB_CHUNK);
+    if (lo >= hi) return;
     const unsigned key = mix32(salted(drop_seed));
-    float acc[NC][8];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    bf16x8 x[NC], nx[NC];
-    long long m = 0, nm = 0;
-    auto fetch = [&](long long k, long long& mm, bf16x8* px) {
-        mm = perm[k];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int col = lane * 8 + 512 * c;
-            px[c] = col < D ? ld_bf16x8(dX + (size_t)mm * ldx + col) : zero8;          // (row padding beyond D is readable)
-        }
-    };
-    long long k = lo + w;
-    if (k < hi) fetch(k, nm, nx);
-    for (; k < hi; k += 4) {
-        m = nm;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) x[c] = nx[c];
-        if (k + 4 < hi) fetch(k + 4, nm, nx);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int col = lane * 8 + 512 * c;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf2f(x[c][e]);
-                if (drop_thr) f = mix32k((unsigned)m * (unsigned)D + (unsigned)(col + e), key) >= drop_thr ? f * drop_scale : 0.f;
-                if (col + e < D) acc[c][e] += f;
+    // id of the first token of the chunk: the largest v with offs[v] <= lo (binary search over the V + 1 offsets)
+    int v = 0;
+    {
+        int a = 0, b = V;          // offs[a] <= lo < offs[b] is maintained where possible (ids outside [0, V): skipped)
+        if (lo < offs[0] || lo >= offs[V]) { a = -1; }
+        else {
+            while (b - a > 1) {
+                const int mid = (a + b) >> 1;
+                if (offs[mid] <= lo) a = mid; else b = mid;
             }
         }
+        v = a;
     }
+    float acc[NC][8];
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
+    for (int cc = 0; cc < NC; ++cc)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[w][lane * 8 + 512 * c + e] = acc[c][e];
-    __syncthreads();
-    float* out = slabs + ((size_t)sp * V + v) * D;
-    for (int i = threadIdx.x; i < D; i += 256) out[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        for (int e = 0; e < 8; ++e) acc[cc][e] = 0.f;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cnt = 0;          // tokens in the current run
+    auto flush = [&](int id) {
+        const bool wr = id >= 0 && id < V && cnt > 0;          // (ids outside the table and empty runs: nothing to store)
+        cnt = 0;
+        float* out = part + (size_t)(wr ? id + c : 0) * D;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const int col = lane * 8 + 512 * cc;
+            if (!wr) {
+            } else if (col + 7 < D) {
+                *(f32x4*)(out + col) = (f32x4){acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]};
+                *(f32x4*)(out + col + 4) = (f32x4){acc[cc][4], acc[cc][5], acc[cc][6], acc[cc][7]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (col + e < D) out[col + e] = acc[cc][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[cc][e] = 0.f;
+        }
+    };
+    long long run_end = (v >= 0 && v < V) ? offs[v + 1] : (lo < offs[0] ? offs[0] : (long long)ntok);
+    // four rows in flight per wave (a row is one dependent round trip: token index -> 1 KB of dX)
+    constexpr int U = 8;
+    for (long long k0 = lo; k0 < hi; k0 += U) {
+        long long mm[U];
+        bf16x8 x[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mm[u] = k0 + u < hi ? perm[k0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+                const int col = lane * 8 + 512 * cc;
+                x[u][cc] = (col < D && k0 + u < hi) ? ld_bf16x8(dX + (size_t)mm[u] * ldx + col) : zero8;      // (row padding beyond D is readable)
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long k = k0 + u;
+            if (k >= hi) break;
+            while (k >= run_end) {          // the run of id v ended before this token: store it, move to the next id
+                flush(v);
+                v = v < 0 ? 0 : v + 1;
+                run_end = v < V ? offs[v + 1] : (long long)ntok;
+            }
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+                const int col = lane * 8 + 512 * cc;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(x[u][cc][e]);
+                    if (drop_thr) f = mix32k((unsigned)mm[u] * (unsigned)D + (unsigned)(col + e), key) >= drop_thr ? f * drop_scale : 0.f;
+                    acc[cc][e] += f;
+                }
+            }
+            ++cnt;
+        }
+    }
+    flush(v);
+}
+
+// pass 2: dE[v][:] = (accumulate ? dE[v][:] : 0) + scale * sum over the chunks that hold tokens of v of part[v + c][:]
+__global__ __launch_bounds__(256) void embed_bwd_fold_kernel(const int64_t* __restrict__ offs, const float* __restrict__ part,
+                                                             float* __restrict__ dE, int D, int V, float scale, int accumulate) {
+    __shared__ f32x4 red[256];
+    const int v = blockIdx.x;
+    const long long b0 = offs[v], b1 = offs[v + 1];
+    const int c0 = (int)(b0 / EMB_CHUNK), c1 = b1 > b0 ? (int)((b1 - 1) / EMB_CHUNK) : c0 - 1;
+    // threads = (column group of 4) x (row lane): a long run (the pad id: hundreds of partial rows) is walked by several
+    // row lanes, eight rows in flight each, and folded through LDS in row-lane order
+    const int ncg = (D + 3) / 4;                       // column groups per pass (D % 4 == 0)
+    const int cgs = ncg < 256 ? ncg : 256;             // column groups handled at once
+    const int nrl = 256 / cgs;                         // row lanes
+    const int cg = threadIdx.x % cgs, rl = threadIdx.x / cgs;
+    for (int colbase = 0; colbase < D; colbase += 4 * cgs) {
+        const int col = colbase + 4 * cg;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (col < D && rl < nrl) {
+            int c = c0 + rl;
+            for (; c + 7 * nrl <= c1; c += 8 * nrl) {
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(part + (size_t)(v + c + u * nrl) * D + col);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += t[u];
+            }
+            for (; c <= c1; c += nrl) a += *(const f32x4*)(part + (size_t)(v + c) * D + col);
+        }
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (rl == 0 && col < D) {
+            for (int r = 1; r < nrl; ++r) a += red[r * cgs + cg];
+            a *= scale;
+            f32x4* dst = (f32x4*)(dE + (size_t)v * D + col);
+            if (accumulate) a += *dst;
+            *dst = a;
+        }
+        __syncthreads();
+    }
 }
 
 // K2: sinusoid table indexed by DISTANCE d (pos = d): out[d] = [sin(d f) | cos(d f)]
@@ -785,16 +871,25 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
     return 0;
 }
 
-extern "C" int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* slabs,
-                                      int nsplit, int D, int V, unsigned drop_seed, float drop_p, hipStream_t stream) {
-    if (V <= 0 || nsplit <= 0 || D > 1024 || ldx < ((D + 7) & ~7) || (ldx % 8)) return -22;
-    const dim3 grid(V, nsplit);
-    if (D <= 512)
-        COMMU_LAUNCH(embed_bwd_sorted_kernel<1>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, slabs, D, V,
-                     nsplit, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
-    else
-        COMMU_LAUNCH(embed_bwd_sorted_kernel<2>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, slabs, D, V,
-                     nsplit, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+/* rows (of D floats) of the workspace commu_embed_bwd_sorted needs for ntok tokens and V ids */
+extern "C" int commu_embed_bwd_ws_rows(int ntok, int V) { return V + (ntok + EMB_CHUNK - 1) / EMB_CHUNK + 1; }
+
+extern "C" int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* ws,
+                                      int ntok, int D, int V, float* dE, float scale, int accumulate, unsigned drop_seed,
+                                      float drop_p, hipStream_t stream) {
+    if (V <= 0 || ntok < 0) return 0;
+    if (D > 1024 || (D % 4) || ldx < ((D + 7) & ~7) || (ldx % 8)) return -22;
+    const int nchunks = (ntok + EMB_CHUNK - 1) / EMB_CHUNK;
+    if (nchunks > 0) {
+        const dim3 grid((nchunks + 3) / 4);
+        if (D <= 512)
+            COMMU_LAUNCH(embed_bwd_runs_kernel<1>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, ws, ntok, D,
+                         V, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+        else
+            COMMU_LAUNCH(embed_bwd_runs_kernel<2>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, ws, ntok, D,
+                         V, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+    }
+    COMMU_LAUNCH(embed_bwd_fold_kernel, dim3(V), dim3(256), 0, stream, offs, ws, dE, D, V, scale, accumulate);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -140,11 +140,15 @@ int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo,
 int commu_embed_bwd(const int64_t* tok, const void* dX_bf16, int ldx, float* dE, int ntok, int D, int V,
                     float scale, int accumulate, unsigned drop_seed, float drop_p, hipStream_t stream);
 /* the same from a token order: perm = stable argsort of tok (int64 [ntok]), offs[v] = first position of id v in the sorted
- * list (int64 [V+1]; ids outside [0, V) fall outside offs[0]..offs[V] and contribute nothing).  Writes
- * slabs[s][V][D] = unscaled (dropout-masked) row sums of split s of every id's tokens, s < nsplit;
- * dE (+)= scale * sum of the slabs is commu_reduce_slabs_f32's.  Fixed summation order, no atomics. */
-int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* slabs, int nsplit,
-                           int D, int V, unsigned drop_seed, float drop_p, hipStream_t stream);
+ * list (int64 [V+1]; ids outside [0, V) fall outside offs[0]..offs[V] and contribute nothing).  Two passes over the
+ * sorted list: every wave sums 32 consecutive sorted tokens run by run into the fp32 workspace `ws`
+ * (commu_embed_bwd_ws_rows(ntok, V) rows of D floats), then dE[v] (+)= scale * (sum of v's partial rows).  The work of a
+ * wave does not depend on how often an id occurs (the pad / start id is a quarter of a real batch); fixed summation order,
+ * no atomics. */
+int commu_embed_bwd_ws_rows(int ntok, int V);
+int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* ws, int ntok, int D,
+                           int V, float* dE, float scale, int accumulate, unsigned drop_seed, float drop_p,
+                           hipStream_t stream);
 /* sinusoid table by distance d: out[d] = [sin(d f) | cos(d f)]  (PositionalEmbedding, model.py:136-152) */
 int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, unsigned drop_seed,
                      float drop_p, hipStream_t stream);

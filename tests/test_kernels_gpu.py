@@ -311,6 +311,8 @@ def test_embed_bwd_token_order(D, ld):
     V, n = 729, 9000
     tok = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(13))
     tok[:300] = 7
+    tok[2000:5500] = 0            # a dominating id (the pad / start token of a real batch): runs across many chunks
+    tok[5500:5600] = V - 1
     tok[300:310] = V + 5          # outside the vocabulary: contribute nothing
     tok[310:320] = -1
     dX = torch.zeros(n, ld, dtype=torch.bfloat16)
