@@ -261,7 +261,7 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
                   "commu_gemm_tn_bf16", "commu_gemm_tn_bf16_grouped", "commu_relattn_bwd_band"]
     # (an event pair around every profiled call costs ~4 % of a step -- ~130 calls -- so only every fourth step of the
     #  timed region is instrumented; time_share scales the sampled sums back to the whole region)
-    _lib.profile_start(prof_names)
+    _lib.profile_start(prof_names, shape_args={"commu_gemm_nt_bf16": (6, 7, 8)})          # (M, N, K) of every NT GEMM
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(steps, warmup, sample_events=True)
@@ -291,8 +291,8 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
     mb_tokens = tokens_per_step // args.batch_chunk
     kbar = M + (T + 1) / 2.0
     products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 3.0}
-    tot = {k: sum(v) for k, v in prof.items()}
-    cnt = {k: max(1, len(v)) for k, v in prof.items()}
+    tot = {k: sum(v) for k, v in prof.items() if ":" not in k}
+    cnt = {k: max(1, len(v)) for k, v in prof.items() if ":" not in k}
     dom = max(products, key=lambda k: tot.get(k, 0.0))
     fl_launch = mb_tokens * products[dom] * 2.0 * kbar * args.d_model
     avg_ms = tot[dom] / cnt[dom]
@@ -366,6 +366,25 @@ def iterator_bench(args, dev, steps, warmup, resident_ms):
             "producer_wait_ms_per_step": round(1e3 * wait / steps, 4),
             "step_rate_vs_resident_batches": round(resident_ms / ms, 4), "steps": steps, "warmup": warmup,
             "corpus": "synthetic ragged (lengths uniform in [T/2, 3T)), on-disk .npy object arrays, shuffled epochs"}
+
+
+def gemm_roofline(prof, elapsed, pscale=1.0):
+    """One roofline row per NT GEMM shape of the step (commu_gemm_nt_bf16: every nn.Linear forward and every dX = dY . W;
+    HIP events around each call on the launching stream, inside the timed region, side streams running):
+    algorithmic flops 2 M N K / mean launch time against the dense bf16 MFMA peak.  Sorted by summed time."""
+    rows = []
+    for key, v in prof.items():
+        if not key.startswith("commu_gemm_nt_bf16:") or not v:
+            continue
+        M, N, K = (int(x) for x in key.split(":")[1].split("x"))
+        avg_ms = sum(v) / len(v)
+        tf = 2.0 * M * N * K / (avg_ms * 1e-3) / 1e12
+        rows.append({"shape_MNK": [M, N, K], "launches_sampled": len(v), "avg_launch_ms": round(avg_ms, 4),
+                     "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
+                     "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                     "time_share": round(pscale * sum(v) / (1e3 * elapsed), 4)})
+    rows.sort(key=lambda r: -r["time_share"])
+    return rows
 
 
 # Further single-GPU rows (VERDICT r1: the shapes that were parity-tested but never timed); a few steps each
@@ -484,6 +503,7 @@ def main():
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
         "roofline": attention_roofline(args, prof, tokens_per_step, elapsed, pscale),
+        "roofline_gemm": gemm_roofline(prof, elapsed, pscale),
     }
     if world == 1 and (args.from_iterator or not args.no_extra):
         out["iterator_fed"] = iterator_bench(args, dev, args.steps, args.warmup, ms_per_step)

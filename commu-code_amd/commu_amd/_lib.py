@@ -146,9 +146,11 @@ def load():
 _prof = None
 
 
-def profile_start(names):
+def profile_start(names, shape_args=None):
+    """shape_args: {entry point: tuple of argument positions} -- calls of that entry point are also recorded per shape
+    under the key "name:a x b x c" (bench.py: one roofline row per GEMM shape)."""
     global _prof
-    _prof = {"names": set(names), "events": {n: [] for n in names}, "on": True}
+    _prof = {"names": set(names), "events": {n: [] for n in names}, "on": True, "shape_args": dict(shape_args or {})}
 
 
 def profile_enable(on: bool):
@@ -178,6 +180,9 @@ def call(name, *args):
         rc = fn(*args)
         e.record()
         _prof["events"][name].append((s, e))
+        pos = _prof["shape_args"].get(name)
+        if pos is not None:
+            _prof["events"].setdefault(name + ":" + "x".join(str(int(args[i])) for i in pos), []).append((s, e))
     else:
         rc = fn(*args)
     if name not in _NOCHECK and rc != 0:
