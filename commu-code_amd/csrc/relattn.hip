@@ -919,8 +919,13 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
     }
     // P scratch for relattn_bwd_kv2_kernel: this (batch, head)'s [ceil(T/16)][ceil(K/64)] blocks of 2 KB
     const int JT = (K + 63) >> 6;
+    // The P stores are issued UNCONDITIONALLY (a wave without rows, or a launch without a P buffer, stores through an
+    // empty descriptor: dropped by the range check).  A store inside an `if` is not counted by the compiler's vmcnt
+    // bookkeeping as certainly younger than the staging loads, so its counted waits for those loads (bottom of the tile)
+    // also waited for this tile's four P stores to be ACKNOWLEDGED -- a round trip to memory per tile.
     const bool pstore = a.pbuf != nullptr && i0 + 16 * w < T;
-    const srd_t srdP = make_srd(a.pbuf + ((size_t)b * a.H + h) * ((T + 15) >> 4) * JT * 1024, (size_t)((T + 15) >> 4) * JT * 2048);
+    const srd_t srdP = make_srd(a.pbuf + ((size_t)b * a.H + h) * ((T + 15) >> 4) * JT * 1024,
+                                pstore ? (size_t)((T + 15) >> 4) * JT * 2048 : 0);
     const int pvoff = pt_off(r16, g) * 2;          // bytes; pt_off(16c + r16, g) = 256 c + pt_off(r16, g)
     int foff[KS];          // fragment addressing: lane part r16 * DH + swizzled chunk (block rows are multiples of 16)
 #pragma unroll
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a
                 pq[reg] = f2bf(p);
             }
             // the key-stationary kernel re-reads P instead of recomputing it (block of 16 rows x 64 keys, P^T image order)
-            if (DH == 64 && pstore)
+            if (DH == 64)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), srdP, pvoff + 512 * c,
                                                       (((iw_lo >> 4) * JT + jt) << 11), 2 /* nt: read once, by a later kernel */);
             *(bf16x4*)(myD + pt_off(16 * c + r16, g)) = db;       // dS^T[kv][row]
