@@ -813,7 +813,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // backward, q-stationary: dq_AC = dS.K (+ its column sums for d r_w_bias) and dS written by
 // DISTANCE (dSk[i][d = i+M-j]) for the two GEMMs  dq_BD = dSk.Rd  and  dRd = dSk^T.(q+v).
 template <int DH, int NW, bool DROP>
-__global__ __launch_bounds__(64 * NW) void relattn_bwd_q_kernel(const AttnArgs a) {
+// (waves_per_eu(2, 2): the kernel sits at the 256-register edge; without the bound a small edit lets the compiler take a
+//  few registers more and the workgroup silently drops to one wave per SIMD -- measured 1.53 -> 1.73 ms per layer pass)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void relattn_bwd_q_kernel(const AttnArgs a) {
     constexpr int KS = DH / 32, DB = DH / 16;
     constexpr int QROWS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // query rows per workgroup, band chunks
     __shared__ __attribute__((aligned(16))) bf16 sK[64 * DH];
