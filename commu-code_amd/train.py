@@ -33,6 +33,9 @@ def parse_args(argv=None):
     p.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
     p.add_argument("--work_dir", type=str, required=True, help="Base directory to save the trained model.")
     # -- not in the reference: overrides of its hard-coded defaults
+    p.add_argument("--graph", action="store_true",
+                   help="replay the optimiser step from hipGraphs once its shapes are steady (not in the reference; pays "
+                        "when a micro-batch is small enough for the host's launch rate to bound the step)")
     p.add_argument("--max_step", type=int, default=None)
     p.add_argument("--log_interval", type=int, default=None)
     p.add_argument("--eval_interval", type=int, default=None)
@@ -100,7 +103,7 @@ def main(argv=None):
     reducer = GradReducer() if world > 1 else None
     if reducer is not None:
         reducer.broadcast_params(model)                                         # DDP constructor semantics (C3)
-    trainer = Trainer(model, cfg, num_gpus=num_gpus, reducer=reducer)
+    trainer = Trainer(model, cfg, num_gpus=num_gpus, reducer=reducer, graph=bool(getattr(args, "graph", False)))
     best_val_nll = float("inf")
 
     def checkpoint(name, val_nll):                                              # train.py:29-54 (C7)
