@@ -263,7 +263,7 @@ class Trainer:
         self.train_step += 1
         self.scheduler.step()
         self.log_token_num += int(batch_token_num)
-        return st["total"]
+        return st["total"].clone()          # (the graph's own output buffer is overwritten by the next replay)
 
     def _sum_over_ranks(self, values):
         """One packed all-reduce for a set of scalars (the reference issues one collective per scalar)."""
