@@ -101,6 +101,10 @@ PROTOTYPES = {
     "commu_decode_kv_append": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_decode_attn": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
+    "commu_decode_tail_supported": [c_i, c_i, c_i, c_i],
+    "commu_decode_tail_sync_words": [],
+    "commu_decode_layer_tail": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_i,
+                                c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "commu_forcing_state_ints": [],
     "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
@@ -111,7 +115,7 @@ PROTOTYPES = {
 _RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
             "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
 _NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
-            "commu_forcing_state_ints", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
+            "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
 
 _lib = None
 

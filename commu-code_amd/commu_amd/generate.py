@@ -23,6 +23,9 @@ from .midi_generator.midi_inferrer import TOKEN_OFFSET, ForcingReport
 
 BF16, F32 = torch.bfloat16, torch.float32
 VPAD = 768
+# decode step: everything after a layer's attention as one launch (commu_decode_layer_tail) where the shape is supported;
+# False: one launch per Linear / LayerNorm (the only path for other shapes)
+USE_LAYER_TAIL = True
 
 
 def _p(t):
@@ -58,6 +61,17 @@ class DecodeState:
         self.logits_new = torch.zeros(B, VPAD, device=dev, dtype=F32)      # this step's logits before the row select
         self.qkv = torch.zeros(B, 3 * HD, device=dev, dtype=BF16)
         self.vec = torch.zeros(B, HD, device=dev, dtype=BF16)
+        # layer-tail launches: hand-off buffers per layer, arrival counters per launch, give-up flag
+        DI = model._DIp
+        self.tail_ok = bool(call("commu_decode_tail_supported", B, D, DI, HD)) and L > 0
+        if self.tail_ok:
+            nw = call("commu_decode_tail_sync_words")
+            self.t_z1 = torch.zeros(L, B, D, device=dev, dtype=BF16)
+            self.t_hid = torch.zeros(L, B, DI, device=dev, dtype=BF16)
+            self.t_z2 = torch.zeros(L, B, D, device=dev, dtype=BF16)
+            self.t_h = torch.zeros(L, B, D, device=dev, dtype=BF16)
+            self.t_sync = torch.zeros(L, nw, device=dev, dtype=torch.int32)
+            self.t_err = torch.zeros(1, device=dev, dtype=torch.int32)
 
     def prefill(self, ctx: torch.Tensor):
         """ctx: int64 [T0, B] context tokens (midi_inferrer.py:186-197): fills the caches with their K/V
@@ -87,6 +101,8 @@ class DecodeState:
         consumes them (commu_gemm_nt_ln_bf16), which also stores the normalised rows for the next residual add."""
         m = self.model
         B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
+        if USE_LAYER_TAIL and self.tail_ok:
+            return self._step_tail(tokens, active, keep, want_logits)
         h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight, ld=D)
         scale = m.attn_scale
         u, vb = m._uv()
@@ -119,6 +135,55 @@ class DecodeState:
                 call("commu_copy_rows_masked_f32", _p(self.logits), VPAD, _p(self.logits_new), VPAD, _p(active),
                      B, V, _s())
         return self.logits
+
+
+    def _step_tail(self, tokens, active, keep, want_logits):
+        """step() with one launch per layer after the attention (csrc/decode_tail.hip): embedding, layer 0's QKV Linear,
+        then per layer [cached attention, layer tail]; the tail of layer i ends with layer i + 1's QKV Linear, the last
+        one with the logits."""
+        m = self.model
+        B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
+        HD, DI = H * DH, m._DIp
+        V = m.n_token
+        self.t_sync.zero_()
+        h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight, ld=D)
+        scale = m.attn_scale
+        u, vb = m._uv()
+        ws = [m._weights(i) for i in range(L)]
+        ops.gemm_nt(h, ws[0]["qkv"], out=self.qkv)
+        dst = self.logits if active is None else self.logits_new
+        for i in range(L):
+            w, lay = ws[i], m.layers[i]
+            call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
+                 _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
+                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, _s())
+            last = i == L - 1
+            if last and not want_logits:
+                break
+            ln1, ln2 = lay.dec_attn.layer_norm, lay.pos_ff.layer_norm
+            if last:
+                wn, nn_, bn, out_n, ld_on, h_out = m._emb_bf16(), V, m.crit.out_layers[0].bias, dst, dst.stride(0), None
+            else:
+                wn, nn_, bn, out_n, ld_on, h_out = ws[i + 1]["qkv"], 3 * HD, None, self.qkv, self.qkv.stride(0), self.t_h[i]
+            call("commu_decode_layer_tail", _p(self.vec), self.vec.stride(0), _p(h), h.stride(0),
+                 _p(w["o"]), w["o"].stride(0), _p(w["w1"]), w["w1"].stride(0), _p(w["b1"]),
+                 _p(w["w2"]), w["w2"].stride(0), _p(w["b2"]), _p(ln1.weight), _p(ln1.bias), float(ln1.eps),
+                 _p(ln2.weight), _p(ln2.bias), float(ln2.eps), ln1.weight.numel(), _p(wn), wn.stride(0), nn_, _p(bn),
+                 1 if last else 0, _p(self.t_z1[i]), _p(self.t_hid[i]), _p(self.t_z2[i]), _p(h_out), D,
+                 _p(out_n), ld_on, B, D, DI, HD, _p(self.t_sync[i]), _p(self.t_err), _s())
+            h = h_out
+        if keep is not None:
+            call("commu_decode_advance", _p(self.klen), _p(keep), B, self.Lmax, _s())
+        if want_logits and active is not None:       # only the rows of the sequences that stepped are replaced
+            call("commu_copy_rows_masked_f32", _p(self.logits), VPAD, _p(self.logits_new), VPAD, _p(active),
+                 B, V, _s())
+        return self.logits
+
+    def check(self):
+        """Raises when a layer-tail launch gave up waiting for its peers (one D2H read: call it outside the loop)."""
+        if self.tail_ok and int(self.t_err.item()) != 0:
+            raise CommuHipError(f"decode layer-tail launch timed out at hand-off {int(self.t_err.item())}: its results are "
+                                "invalid")
 
 
 class ForcedDecoder:
@@ -275,6 +340,7 @@ class ForcedDecoder:
             it += self.POLL
             if bool(self.fsm[:, 5].all().item()):          # every record's `done` flag (the one sync per POLL steps)
                 break
+        self.state.check()
 
     def sequences(self):
         """Token lists (None where nothing could be drawn, Q12) and, per sequence, the model-step trace

@@ -330,6 +330,24 @@ int commu_decode_attn(const void* qkv, int ld_qkv, void* kcache, void* vcache, c
                       float scale, int append, hipStream_t stream);
 /* klen[b] += advance[b]  (a step whose memory the reference discards does not advance: quirk Q3) */
 int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lmax, hipStream_t stream);
+/* Everything of a decode-step layer that follows its attention, as ONE launch (csrc/decode_tail.hip):
+ *   z1 = vec . Wo^T + h;  a = LN1(z1);  hid = relu(a . W1^T + b1);  z2 = hid . W2^T + b2 + a;  h_out = LN2(z2)
+ *   (o_net + residual + LayerNorm model.py:344-352, PositionwiseFF model.py:163-179)
+ * and then out_n = h_out . Wn^T: the NEXT layer's qkv_net (logits == 0: Nn = 3 HD, bf16, model.py:297-299) or the
+ * tied-embedding logits (logits != 0: + bn, fp32, columns < Nn, model.py:64-73).  vec [B][HD], h / h_out [B][D] bf16;
+ * z1 / z2 [B][D] and hid [B][DI] are dense bf16 hand-off buffers that belong to THIS layer; sync:
+ * commu_decode_tail_sync_words() arrival counters that must be ZERO on entry (one set per launch of a step); *err
+ * becomes non-zero when a workgroup gave up waiting (the results of that launch are then invalid).
+ * commu_decode_tail_supported(B, D, DI, HD) names the shapes this build takes (others: -22; callers use the
+ * per-Linear launches).  d_ln: LayerNorm width (<= D; zero-padded models). */
+int commu_decode_tail_supported(int B, int D, int DI, int HD);
+int commu_decode_tail_sync_words(void);
+int commu_decode_layer_tail(const void* vec, int ld_vec, const void* h, int ld_h, const void* Wo, int ld_wo,
+                            const void* W1, int ld_w1, const float* b1, const void* W2, int ld_w2, const float* b2,
+                            const float* g1, const float* be1, float eps1, const float* g2, const float* be2,
+                            float eps2, int d_ln, const void* Wn, int ld_wn, int Nn, const float* bn, int logits,
+                            void* z1, void* hid, void* z2, void* h_out, int ld_ho, void* out_n, int ld_on, int B,
+                            int D, int DI, int HD, unsigned* sync, unsigned* err, hipStream_t stream);
 
 /* ---- device-resident chord / bar forcing of the decode loop (InferenceTask.generate_sequence +
  * TeacherForceTask, commu/midi_generator/midi_inferrer.py:239-320, :16-144): per-sequence state records of

@@ -356,3 +356,54 @@ def test_cached_decode_at_long_memory_vs_oracle(shape):
     print(f"long-memory decode {shape}: worst logit error {worst:.2e} of range, min top1-top2 gap {min(gaps):.3f}, "
           f"{checked}/{len(gaps)} greedy tokens checked exact")
     assert checked >= len(gaps) // 2
+
+
+@pytest.mark.parametrize("B,loaded", [(64, False), (64, True), (37, False), (3, True)])
+def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded):
+    """commu_decode_layer_tail (four Linears + two LayerNorms of a layer as phases of one launch, hand-offs between
+    workgroups inside the launch) against the chain of per-Linear launches it replaces, on the same model, caches and
+    tokens, for 160 consecutive steps: every step's logits within bf16 rounding of each other (a stale or torn hand-off
+    would be an O(1) error in some row), the caches equal at the end, no workgroup gave up.  `loaded`: a second stream
+    keeps the GPU busy with large GEMMs meanwhile, so the workgroups of a launch start and run unevenly."""
+    import commu_amd.generate as G
+    from test_configs_gpu import build
+    model, cfg, s, params = build(6, 8, 512, 1024, 1, 4146, seed=23)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    g = torch.Generator().manual_seed(5 + B)
+    ctx = torch.randint(2, 729, (11, B), generator=g).to(DEV)
+    NSTEP = 160
+    toks = torch.randint(2, 729, (NSTEP, B), generator=g).to(DEV)
+    acts = (torch.rand(NSTEP, B, generator=g) < 0.9).to(torch.uint8).to(DEV)
+    st_a, st_b = G.DecodeState(model, B, 11 + NSTEP + 8), G.DecodeState(model, B, 11 + NSTEP + 8)
+    assert st_a.tail_ok
+    st_a.prefill(ctx)
+    st_b.prefill(ctx)
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device=DEV, dtype=torch.bfloat16)
+    worst = 0.0
+    for i in range(NSTEP):
+        if loaded and i % 4 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    big @ big
+        assert G.USE_LAYER_TAIL
+        la = st_a.step(toks[i], acts[i], acts[i]).clone()
+        G.USE_LAYER_TAIL = False
+        try:
+            lb = st_b.step(toks[i], acts[i], acts[i]).clone()
+        finally:
+            G.USE_LAYER_TAIL = True
+        rng = float(lb[:, :729].abs().max())
+        err = float((la[:, :729] - lb[:, :729]).abs().max()) / rng
+        worst = max(worst, err)
+        assert err < 1e-2, (i, err)
+    torch.cuda.synchronize()
+    st_a.check()
+    assert torch.equal(st_a.klen, st_b.klen)
+    kerr = float((st_a.kc.float() - st_b.kc.float()).abs().max()) / float(st_b.kc.float().abs().max())
+    verr = float((st_a.vc.float() - st_b.vc.float()).abs().max()) / float(st_b.vc.float().abs().max())
+    print(f"layer tail vs per-Linear chain, B={B}, loaded={loaded}: worst logit difference {worst:.2e} of range, "
+          f"K cache {kerr:.2e}, V cache {verr:.2e}")
+    assert kerr < 2e-2 and verr < 2e-2
