@@ -129,8 +129,7 @@ def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
                     if graph:
                         dec.graph.replay()
                     else:
-                        dec.body()
-                        dec.pre()
+                        dec.body_pre()
                 done += dec.POLL
                 live = not bool(dec.fsm[:, 5].all().item())
             return done, live

@@ -104,10 +104,14 @@ PROTOTYPES = {
     "commu_decode_tail_supported": [c_i, c_i, c_i, c_i],
     "commu_decode_tail_sync_words": [],
     "commu_decode_layer_tail": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_i,
-                                c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+                                c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p,
+                                c_p],
+    "commu_decode_head": [c_p, c_p, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "commu_forcing_state_ints": [],
     "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "commu_decode_sample_post_pre": [c_p, c_i, c_i, c_p, c_f, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i,
+                                     c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_pack_batch": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_p, c_p],
     "commu_hip_version": [],

@@ -12,6 +12,7 @@ divided by the temperature when the previous draw was a rejected chord, quirk Q5
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -70,6 +71,7 @@ class DecodeState:
             self.t_hid = torch.zeros(L, B, DI, device=dev, dtype=BF16)
             self.t_z2 = torch.zeros(L, B, D, device=dev, dtype=BF16)
             self.t_h = torch.zeros(L, B, D, device=dev, dtype=BF16)
+            self.t_h0 = torch.zeros(B, D, device=dev, dtype=BF16)
             self.t_sync = torch.zeros(L, nw, device=dev, dtype=torch.int32)
             self.t_err = torch.zeros(1, device=dev, dtype=torch.int32)
 
@@ -145,13 +147,15 @@ class DecodeState:
         B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
         HD, DI = H * DH, m._DIp
         V = m.n_token
-        self.t_sync.zero_()
-        h = ops.embed_fwd(tokens, m.word_emb.emb_layers[0].weight, ld=D)
+        E = m.word_emb.emb_layers[0].weight
         scale = m.attn_scale
         u, vb = m._uv()
         ws = [m._weights(i) for i in range(L)]
-        ops.gemm_nt(h, ws[0]["qkv"], out=self.qkv)
-        dst = self.logits if active is None else self.logits_new
+        h = self.t_h0
+        call("commu_decode_head", _p(tokens), _p(E), E.shape[1], E.shape[0], math.sqrt(E.shape[1]), _p(ws[0]["qkv"]),
+             ws[0]["qkv"].stride(0), _p(h), D, _p(self.qkv), self.qkv.stride(0), B, D, DI, HD, _p(self.t_sync),
+             self.t_sync.numel(), _s())
+        dst = self.logits          # (the logits launch skips the rows of the sequences that did not step)
         for i in range(L):
             w, lay = ws[i], m.layers[i]
             call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
@@ -169,14 +173,11 @@ class DecodeState:
                  _p(w["o"]), w["o"].stride(0), _p(w["w1"]), w["w1"].stride(0), _p(w["b1"]),
                  _p(w["w2"]), w["w2"].stride(0), _p(w["b2"]), _p(ln1.weight), _p(ln1.bias), float(ln1.eps),
                  _p(ln2.weight), _p(ln2.bias), float(ln2.eps), ln1.weight.numel(), _p(wn), wn.stride(0), nn_, _p(bn),
-                 1 if last else 0, _p(self.t_z1[i]), _p(self.t_hid[i]), _p(self.t_z2[i]), _p(h_out), D,
+                 1 if last else 0, _p(active), _p(self.t_z1[i]), _p(self.t_hid[i]), _p(self.t_z2[i]), _p(h_out), D,
                  _p(out_n), ld_on, B, D, DI, HD, _p(self.t_sync[i]), _p(self.t_err), _s())
             h = h_out
         if keep is not None:
             call("commu_decode_advance", _p(self.klen), _p(keep), B, self.Lmax, _s())
-        if want_logits and active is not None:       # only the rows of the sequences that stepped are replaced
-            call("commu_copy_rows_masked_f32", _p(self.logits), VPAD, _p(self.logits_new), VPAD, _p(active),
-                 B, V, _s())
         return self.logits
 
     def check(self):
@@ -232,8 +233,9 @@ class ForcedDecoder:
         self.n_cond = 0
 
     # ---- one loop iteration = decide (pre) -> model step -> sampling step -> book-keeping (post), as kernel launches
-    # on the current stream.  The captured graph holds [step, sample, post, pre of the NEXT iteration]: run() issues
-    # the very first `pre` on its own, so a replay is four stages and the kernel sequence is the same as eager.
+    # on the current stream.  The captured graph holds [step, {sample, post, pre of the NEXT iteration} as one launch]
+    # (body_pre): run() issues the very first `pre` on its own and the kernel sequence is the same captured or not.
+    # pre() / body() are the separate launches (iteration(): tests look at the draws between the stages).
     def pre(self):
         call("commu_forcing_pre", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_tok), _p(self.chord_pos),
              self.ld_chord, _p(self.wrong), _p(self.utable), self.ld_u, self.generation_length, _p(self.tok),
@@ -249,6 +251,17 @@ class ForcedDecoder:
         call("commu_forcing_post", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_pos), self.ld_chord,
              _p(self.wrong), _p(self.draw), _p(self.token), None, _p(self.state.klen), _p(self.keep), self.state.Lmax,
              B, _s())
+
+    def body_pre(self):
+        """body() followed by pre() with the three per-sequence stages (sampling step, post, pre) as one launch: what
+        run() issues per iteration, captured or not."""
+        st = self.state
+        st.step(self.tok, self.active, None)
+        call("commu_decode_sample_post_pre", _p(st.logits), st.logits.stride(0), TOKEN_OFFSET.VOCAB_SIZE, _p(self.wrong),
+             self.temperature, self.top_k, _p(self.token), None, 0, _p(self.fsm), _p(self.seq), self.ld_seq,
+             _p(self.chord_tok), _p(self.chord_pos), self.ld_chord, _p(self.utable), self.ld_u, self.generation_length,
+             _p(self.tok), _p(self.active), _p(self.keep), _p(self.draw), _p(self.uni), _p(self.trace), self.ld_trace,
+             _p(st.klen), st.Lmax, self.B, _s())
 
     def iteration(self, want_probs: bool = False):
         """One complete iteration, eagerly (tests inspect the draws between iterations)."""
@@ -266,13 +279,11 @@ class ForcedDecoder:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self.body()
-            self.pre()
+            self.body_pre()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.body()
-            self.pre()
+            self.body_pre()
         for dst, src in zip(bufs, saved):
             dst.copy_(src)
         if tr is not None:
@@ -335,8 +346,7 @@ class ForcedDecoder:
                 if use_graph:
                     self.graph.replay()
                 else:
-                    self.body()
-                    self.pre()
+                    self.body_pre()
             it += self.POLL
             if bool(self.fsm[:, 5].all().item()):          # every record's `done` flag (the one sync per POLL steps)
                 break

@@ -1,0 +1,308 @@
+// Per-sequence stages of the decode loop iteration as device functions (one 64-lane wave per sequence), shared by the
+// stand-alone kernels (sample.hip, forcing.hip) and the fused sample -> post -> pre launch (forcing.hip).
+#pragma once
+#include "common.cuh"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ sampling step (K15)
+constexpr int PER_LANE = 12;      // 64 * 12 = 768 >= 729: lane l owns ids [12 l, 12 l + 12)
+
+// one wave per sequence b (lane = threadIdx.x of a 64-thread workgroup)
+__device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restrict__ logits, int ld, int V,
+                                                 const unsigned char* __restrict__ wrong, int ldw,
+                                                 const float* __restrict__ uni,
+                                                 const unsigned char* __restrict__ active, float temperature,
+                                                 int top_k, int* __restrict__ token, float* __restrict__ probs_out,
+                                                 int ldp) {
+    if (active != nullptr && !active[b]) return;
+    float* lg = logits + (size_t)b * ld;
+    float p[PER_LANE];
+    const int base = lane * PER_LANE;
+    // ---- calc_probs
+    if (temperature == 0.f) {
+        float best = -INFINITY;
+        int bi = V;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            const int id = base + e;
+            if (id >= 1 && id < V && lg[id] > best) { best = lg[id]; bi = id; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) p[e] = (base + e == bi) ? 1.f : 0.f;
+    } else {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            const int id = base + e;
+            float x = -INFINITY;
+            if (id >= 1 && id < V) {
+                x = lg[id] / temperature;
+                lg[id] = x;                     // in-place division: compounds on a redo (Q5)
+            }
+            p[e] = x;
+            mx = fmaxf(mx, x);
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            p[e] = (p[e] == -INFINITY) ? 0.f : expf(p[e] - mx);
+            s += p[e];
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) p[e] *= inv;
+    }
+    // ---- apply_sampling: top-k (ties: lowest id first).  Probabilities are >= 0, so their bit patterns order like the
+    // values: the k-th largest is found by a 32-step radix select whose counts are wave ballots + scalar popcounts (no
+    // cross-lane data movement, ~1 us), instead of k rounds of a wave arg-max (12 LDS / DPP exchanges each: ~19 us at
+    // k = 32); elements equal to the threshold are admitted in id order until k are kept.
+    unsigned keep = 0u, wmask = 0u;          // wmask: the rejected ("wrong") tokens of this lane, read before the selection
+    if (wrong != nullptr) {
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e)
+            if (base + e < V && wrong[(size_t)b * ldw + base + e] != 0) wmask |= 1u << e;
+    }
+    {
+        unsigned key[PER_LANE];
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) key[e] = (base + e < V) ? __float_as_uint(p[e]) : 0u;
+        unsigned thr = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = thr | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < PER_LANE; ++e) cnt += __popcll(__ballot(key[e] >= cand));
+            if (cnt >= top_k) thr = cand;
+        }
+        int ngt = 0, neq_lane = 0;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            ngt += __popcll(__ballot(key[e] > thr));
+            neq_lane += (key[e] == thr && base + e < V) ? 1 : 0;
+        }
+        // exclusive prefix of the per-lane tie counts in lane (= id) order
+        int incl = neq_lane;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        int rank = incl - neq_lane;
+        const int room = top_k - ngt;          // ties admitted
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            if (key[e] > thr) keep |= 1u << e;
+            else if (key[e] == thr && base + e < V) {
+                if (rank < room) keep |= 1u << e;
+                ++rank;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < PER_LANE; ++e) {
+        const int id = base + e;
+        const bool k = (((keep & ~wmask) >> e) & 1u) && id < V;
+        p[e] = k ? p[e] : 0.f;
+        s += p[e];
+    }
+    const float tot = wave_sum(s);
+    if (!(tot > 0.f)) {                          // NaN / zero mass: the reference's multinomial raises
+        if (lane == 0) token[b] = -1;
+        if (probs_out != nullptr)
+            for (int e = 0; e < PER_LANE; ++e)
+                if (base + e < V) probs_out[(size_t)b * ldp + base + e] = NAN;
+        return;
+    }
+    const float inv = 1.f / tot;
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < PER_LANE; ++e) { p[e] *= inv; ls += p[e]; }
+    if (probs_out != nullptr)
+        for (int e = 0; e < PER_LANE; ++e)
+            if (base + e < V) probs_out[(size_t)b * ldp + base + e] = p[e];
+    // ---- infer_token: smallest id with cdf[id] > u
+    float incl = ls;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const float excl = incl - ls;
+    const float u = uni != nullptr ? uni[b] : 0.5f;
+    int cand = 1 << 30;
+    float c = excl;
+#pragma unroll
+    for (int e = 0; e < PER_LANE; ++e) {
+        c += p[e];
+        if (p[e] > 0.f && c > u && cand == (1 << 30)) cand = base + e;
+    }
+    // fall-back for u above the accumulated total (rounding): the last token with mass
+    int last = -1;
+#pragma unroll
+    for (int e = 0; e < PER_LANE; ++e)
+        if (p[e] > 0.f) last = base + e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cand = min(cand, __shfl_xor(cand, o, 64));
+        last = max(last, __shfl_xor(last, o, 64));
+    }
+    if (lane == 0) token[b] = (cand == (1 << 30)) ? last : cand;
+}
+
+
+// ------------------------------------------------------------------------------------------------ forcing rules
+constexpr int TOK_EOS = 1, TOK_BAR = 2, TOK_CHORD_LO = 195, TOK_CHORD_HI = 303, TOK_POS0 = 432, POS_RES = 128;
+constexpr int VOCAB = 729;
+
+// field indices of the int32 state record (commu_forcing_state_ints() ints per sequence)
+enum {
+    F_LEN = 0,      // tokens in seq
+    F_FORCED,       // token to feed next iteration, -1: none  (next_tokens_forced holds at most one token)
+    F_REDO,         // no_sequence_appended: draw again from the current logits
+    F_FIRST,        // first model step after the context: its memory is discarded
+    F_FILLED,       // incomplete_filled
+    F_DONE,
+    F_FAILED,       // nothing could be drawn (Q12)
+    F_ITERS,
+    F_NBAR,         // seq.count(BAR)
+    F_NCHORD,       // chord_length
+    F_CUR,          // chords consumed so far
+    F_LENGTH_FIT,   // chord_length == int(num_measures // 4 * 4)
+    F_NDRAW,        // uniform variates consumed
+    F_NTRACE,       // model steps recorded
+    F_COUNT
+};
+
+__device__ __forceinline__ void forcing_pre_body(int b, int lane, int* st, int* seq, int ld_seq,
+                                                 const int* __restrict__ chord_tok, const int* __restrict__ chord_pos,
+                                                 int ld_chord, unsigned char* wrong, const float* __restrict__ utable,
+                                                 int ld_u, int max_iters, long long* tok, unsigned char* active,
+                                                 unsigned char* keep, unsigned char* draw, float* uni, int* trace,
+                                                 int ld_trace) {
+    int* s = st + (size_t)b * F_COUNT;
+    int* sq = seq + (size_t)b * ld_seq;
+    int clear = 0;
+    if (lane == 0) {
+        int act = 0, kp = 0, dr = 0;
+        long long t = 0;
+        const int len = s[F_LEN];
+        const int last = sq[len - 1], prev = len >= 2 ? sq[len - 2] : -1;
+        if (!s[F_DONE] && (s[F_ITERS] >= max_iters || last == TOK_EOS || len >= ld_seq)) s[F_DONE] = 1;
+        if (!s[F_DONE]) {
+            s[F_ITERS] += 1;
+            if (s[F_FORCED] >= 0) {                                     // midi_inferrer.py:247-251
+                const int f = s[F_FORCED];
+                s[F_FORCED] = -1;
+                sq[len] = f;
+                s[F_LEN] = len + 1;
+                if (f == TOK_BAR) s[F_NBAR] += 1;
+                t = f; act = 1; kp = 1;
+            } else {
+                if (s[F_REDO]) {                                        // :253-255
+                    s[F_REDO] = 0;
+                } else if (s[F_FIRST]) {                                // :256-258
+                    s[F_FIRST] = 0;
+                    t = last; act = 1; kp = 0;
+                } else {                                                // :259-260
+                    t = last; act = 1; kp = 1;
+                }
+                if (!s[F_FILLED]) s[F_FILLED] = s[F_NBAR] > 1;          // :267-268
+                const int cur = s[F_CUR];
+                const bool remnant = cur < s[F_NCHORD];
+                bool decided = false;
+                if (s[F_FILLED] && last == TOK_BAR) {                   // :271-273
+                    s[F_FORCED] = TOK_POS0;
+                    decided = true;
+                } else if (remnant && s[F_FILLED]) {                    // :276-283
+                    const int cp = chord_pos[(size_t)b * ld_chord + cur];
+                    const bool posfit = prev == TOK_BAR && last == TOK_POS0;
+                    const bool due = s[F_LENGTH_FIT] ? posfit : (posfit || (last == cp && cp != TOK_POS0));
+                    if (due) {
+                        s[F_FORCED] = chord_tok[(size_t)b * ld_chord + cur];
+                        s[F_CUR] = cur + 1;
+                        clear = 1;
+                        decided = true;
+                    }
+                }
+                if (!decided) {
+                    dr = 1;
+                    const int nd = s[F_NDRAW];
+                    uni[b] = utable[(size_t)b * ld_u + (nd < ld_u ? nd : ld_u - 1)];
+                    s[F_NDRAW] = nd + 1;
+                }
+            }
+            if (act && trace != nullptr) {
+                const int nt = s[F_NTRACE];
+                if (2 * nt + 1 < ld_trace) {
+                    trace[(size_t)b * ld_trace + 2 * nt] = (int)t;
+                    trace[(size_t)b * ld_trace + 2 * nt + 1] = kp;
+                }
+                s[F_NTRACE] = nt + 1;
+            }
+        }
+        tok[b] = t;
+        active[b] = (unsigned char)act;
+        keep[b] = (unsigned char)kp;
+        draw[b] = (unsigned char)dr;
+    }
+    clear = __shfl(clear, 0, 64);
+    if (clear)
+        for (int i = lane; i < VOCAB; i += 64) wrong[(size_t)b * VOCAB + i] = 0;
+}
+
+__device__ __forceinline__ void forcing_post_body(int b, int lane, int* st, int* seq, int ld_seq,
+                                                  const int* __restrict__ chord_pos, int ld_chord, unsigned char* wrong,
+                                                  const unsigned char* draw, const int* token, int* live, int* klen,
+                                                  const unsigned char* keep, int lmax) {
+    int* s = st + (size_t)b * F_COUNT;
+    int clear = 0;
+    if (lane == 0) {
+        // memory length of the step that just ran: it grows unless the step's memory is discarded (quirk Q3)
+        if (klen != nullptr && keep[b] && klen[b] < lmax - 1) klen[b] += 1;
+        if (draw[b]) {
+            const int t = token[b];
+            const int cur = s[F_CUR];
+            const bool remnant = cur < s[F_NCHORD];
+            const int cp = remnant ? chord_pos[(size_t)b * ld_chord + cur] : -1;
+            const bool inter = remnant && cp != TOK_POS0;
+            if (t < 0) {                                                                  // :286-291, Q12
+                s[F_FAILED] = 1;
+                s[F_DONE] = 1;
+            } else if (inter && ((cp < t && t < TOK_POS0 + POS_RES) || t == TOK_BAR)) {    // :294-296
+                s[F_FORCED] = cp;
+                clear = 1;
+            } else if (t >= TOK_CHORD_LO && t <= TOK_CHORD_HI) {                           // :299-301
+                s[F_REDO] = 1;
+                wrong[(size_t)b * VOCAB + t] = 1;
+            } else if (remnant && t == TOK_EOS) {                                         // :304-306
+                s[F_FORCED] = inter ? cp : TOK_BAR;
+            } else if (!remnant && t == TOK_BAR) {                                        // :309-311
+                s[F_FORCED] = TOK_EOS;
+            } else {
+                const int len = s[F_LEN];
+                if (len < ld_seq) {
+                    seq[(size_t)b * ld_seq + len] = t;
+                    s[F_LEN] = len + 1;
+                }
+                if (t == TOK_BAR) s[F_NBAR] += 1;
+            }
+        }
+        if (live != nullptr && !s[F_DONE]) atomicAdd(live, 1);
+    }
+    clear = __shfl(clear, 0, 64);
+    if (clear)
+        for (int i = lane; i < VOCAB; i += 64) wrong[(size_t)b * VOCAB + i] = 0;
+}
+
+
+}  // namespace

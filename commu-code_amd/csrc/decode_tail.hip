@@ -26,6 +26,7 @@
 // the wait that ends phase p, so that the wait hides their latency.
 #include "common.cuh"
 #include "commu_hip.h"
+#include <string.h>
 
 namespace {
 
@@ -57,7 +58,16 @@ struct TailArgs {
     int B;
     unsigned* sync;                         // [3][4] arrival counters of this launch, zero on entry
     unsigned* err;
+    const unsigned char* active;            // (logits) rows with active[row] == 0 keep their previous logits; null: all
+    // head launch (MODE_HEAD): x = E32[tok[row]] * emb_scale instead of LN2(z2); zero_words[0 .. n_zero) are cleared
+    const int64_t* tok;
+    const float* E32;
+    int d_true, V;
+    float emb_scale;
+    unsigned* zero_words;
+    int n_zero;
 };
+enum { MODE_QKV = 0, MODE_LOGITS = 1, MODE_HEAD = 2 };
 
 template <int KS>
 __device__ __forceinline__ void load_x(bf16x8 (&xf)[KS], srd_t srd, unsigned off, bool sc1) {
@@ -182,8 +192,9 @@ __device__ __forceinline__ void store4_sc1(srd_t srd, unsigned off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), srd, (int)off, 0, AUX_SC1);
 }
 
-template <int D, int DI, int HD, bool LOGITS>
+template <int D, int DI, int HD, int MODE>
 __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
+    constexpr bool LOGITS = MODE == MODE_LOGITS, HEAD = MODE == MODE_HEAD;
     constexpr int KS_D = D / 128, KS_DI = DI / 128, KS_HD = HD / 128;        // 32-wide MFMA steps per wave (4 waves split K)
     constexpr int NT1 = D / 512, NT2 = DI / 512, NT3 = D / 512, NT4 = LOGITS ? 2 : (3 * HD) / 512;
     static_assert(D % 512 == 0 && DI % 512 == 0 && HD % 512 == 0 && NT2 <= 3 && NT4 <= 3 && NT1 == 1, "shape");
@@ -199,8 +210,10 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
     const int own_w = (16 * ng) / (32 * KS_D), own_ks = ((16 * ng) % (32 * KS_D)) / 32, own_g2 = ((16 * ng) % 32) / 16;
     const bool own = (w == own_w) && ((g >> 1) == own_g2);
 
+    if (HEAD && blockIdx.x == 0)
+        for (int i = tid; i < a.n_zero; i += 256) a.zero_words[i] = 0u;
     // ---------------------------------------------------------------- phase 1: z1 = vec . Wo^T + h
-    {
+    if (!HEAD) {
         const int k0 = w * (32 * KS_HD) + 8 * g;
         bf16x8 wf[NT1][KS_HD], xf[KS_HD];
         load_w<KS_HD, NT1>(wf, a.Wo, a.ld_wo, D, ng, r16, k0);
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
         arrive(cnt + 0);
     }
     // ---------------------------------------------------------------- phase 2: a = LN1(z1); hid = relu(a . W1^T + b1)
-    {
+    if (!HEAD) {
         const int k0 = w * (32 * KS_D) + 8 * g;
         bf16x8 wf[NT2][KS_D], xf[KS_D];
         float gm[KS_D][8], bt[KS_D][8];
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
         arrive(cnt + 4);
     }
     // ---------------------------------------------------------------- phase 3: z2 = hid . W2^T + b2 + a
-    {
+    if (!HEAD) {
         const int k0 = w * (32 * KS_DI) + 8 * g;
         bf16x8 wf[NT3][KS_DI], xf[KS_DI];
         load_w<KS_DI, NT3>(wf, a.W2, a.ld_w2, D, ng, r16, k0);
@@ -268,23 +281,43 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
         bf16x8 wf[NT4][KS_D], xf[KS_D];
         float gm[KS_D][8], bt[KS_D][8];
         load_w<KS_D, NT4>(wf, a.Wn, a.ld_wn, a.Nn, ng, r16, k0);
-        load_affine<KS_D>(gm, bt, a.g2, a.be2, a.d_ln, k0);
+        if (!HEAD) load_affine<KS_D>(gm, bt, a.g2, a.be2, a.d_ln, k0);
         const int col = 16 * (ng + NGRP * w) + 4 * g;
         f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (LOGITS && w < NT4 && a.bn != nullptr) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) bias[e] = col + e < a.Nn ? a.bn[col + e] : 0.f;
         }
-        wait_arrivals(cnt + 8, a.err, 3u);
-        load_x<KS_D>(xf, make_srd(a.z2, (size_t)B * D * 2), ((unsigned)row * D + k0) * 2u, true);
-        layer_norm<KS_D>(xf, gm, bt, a.d_ln, a.eps2, st, w, r16, g, k0);
+        if (HEAD) {
+            // x = E[tok[row]] * sqrt(d_model) (commu/model/model.py:409-420); an id outside the vocabulary poisons its row
+            // with NaN, like commu_embed_fwd
+            const long long id = row < B ? a.tok[row] : 0;
+            const bool bad = id < 0 || id >= a.V;
+            const float* src = a.E32 + (size_t)(bad ? 0 : id) * a.d_true;
+#pragma unroll
+            for (int ks = 0; ks < KS_D; ++ks) {
+                const int kk = k0 + 32 * ks;
+                f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (kk < a.d_true) v0 = *(const f32x4*)(src + kk);
+                if (kk + 4 < a.d_true) v1 = *(const f32x4*)(src + kk + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = bad ? __builtin_nanf("") : (e < 4 ? v0[e & 3] : v1[e & 3]) * a.emb_scale;
+                    xf[ks][e] = f2bf(kk + e < a.d_true ? x : 0.f);
+                }
+            }
+        } else {
+            wait_arrivals(cnt + 8, a.err, 3u);
+            load_x<KS_D>(xf, make_srd(a.z2, (size_t)B * D * 2), ((unsigned)row * D + k0) * 2u, true);
+            layer_norm<KS_D>(xf, gm, bt, a.d_ln, a.eps2, st, w, r16, g, k0);
+        }
         if (own && row < B && a.h_out != nullptr) {
 #pragma unroll
             for (int ks = 0; ks < KS_D; ++ks)
                 if (ks == own_ks) st_bf16x8(a.h_out + (size_t)row * a.ld_ho + 16 * ng + 8 * (g & 1), xf[ks]);
         }
         multiply<KS_D, NT4>(wf, xf, red, w, lane);
-        if (w < NT4 && row < B && col < a.Nn) {
+        if (w < NT4 && row < B && col < a.Nn && !(LOGITS && a.active != nullptr && !a.active[row])) {
             f32x4 v = tile_sum(red, w, lane);
             if (LOGITS) {
                 float* o = (float*)a.out_n + (size_t)row * a.ld_on + col;
@@ -307,19 +340,25 @@ extern "C" int commu_decode_tail_supported(int B, int D, int DI, int HD) {
 
 extern "C" int commu_decode_tail_sync_words(void) { return 12; }
 
+static TailArgs tail_args_zero() {
+    TailArgs a;
+    memset(&a, 0, sizeof(a));
+    return a;
+}
+
 extern "C" int commu_decode_layer_tail(const void* vec, int ld_vec, const void* h, int ld_h, const void* Wo, int ld_wo,
                                        const void* W1, int ld_w1, const float* b1, const void* W2, int ld_w2,
                                        const float* b2, const float* g1, const float* be1, float eps1, const float* g2,
                                        const float* be2, float eps2, int d_ln, const void* Wn, int ld_wn, int Nn,
-                                       const float* bn, int logits, void* z1, void* hid, void* z2, void* h_out, int ld_ho,
-                                       void* out_n, int ld_on, int B, int D, int DI, int HD, unsigned* sync,
-                                       unsigned* err, hipStream_t stream) {
+                                       const float* bn, int logits, const unsigned char* active, void* z1, void* hid,
+                                       void* z2, void* h_out, int ld_ho, void* out_n, int ld_on, int B, int D, int DI,
+                                       int HD, unsigned* sync, unsigned* err, hipStream_t stream) {
     if (!commu_decode_tail_supported(B, D, DI, HD)) return -22;
     if (d_ln <= 0 || d_ln > D || (ld_vec % 8) || (ld_h % 4) || (ld_wo % 8) || (ld_w1 % 8) || (ld_w2 % 8) || (ld_wn % 8) ||
         (ld_ho % 8) || (ld_on % 4) || sync == nullptr || err == nullptr)
         return -22;
     if (logits ? (Nn < 1 || Nn > 1024) : (Nn != 3 * HD)) return -22;
-    TailArgs a;
+    TailArgs a = tail_args_zero();
     a.vec = (const bf16*)vec; a.ld_vec = ld_vec;
     a.h = (const bf16*)h; a.ld_h = ld_h;
     a.Wo = (const bf16*)Wo; a.ld_wo = ld_wo;
@@ -332,10 +371,27 @@ extern "C" int commu_decode_layer_tail(const void* vec, int ld_vec, const void* 
     a.z1 = (bf16*)z1; a.hid = (bf16*)hid; a.z2 = (bf16*)z2;
     a.h_out = (bf16*)h_out; a.ld_ho = ld_ho;
     a.out_n = out_n; a.ld_on = ld_on;
-    a.B = B; a.sync = sync; a.err = err;
+    a.B = B; a.sync = sync; a.err = err; a.active = active;
     const dim3 grid(NGRP * ((B + 15) / 16));
-    if (logits) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, true>), grid, dim3(256), 0, stream, a);
-    else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, false>), grid, dim3(256), 0, stream, a);
+    if (logits) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_LOGITS>), grid, dim3(256), 0, stream, a);
+    else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_QKV>), grid, dim3(256), 0, stream, a);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_decode_head(const int64_t* tok, const float* E, int d_true, int V, float scale, const void* Wqkv,
+                                 int ld_w, void* h_out, int ld_ho, void* qkv, int ld_qkv, int B, int D, int DI, int HD,
+                                 unsigned* zero_words, int n_zero, hipStream_t stream) {
+    if (!commu_decode_tail_supported(B, D, DI, HD)) return -22;
+    if (d_true <= 0 || d_true > D || (d_true % 4) || (ld_w % 8) || (ld_ho % 8) || (ld_qkv % 4) || h_out == nullptr) return -22;
+    TailArgs a = tail_args_zero();
+    a.tok = tok; a.E32 = E; a.d_true = d_true; a.V = V; a.emb_scale = scale;
+    a.Wn = (const bf16*)Wqkv; a.ld_wn = ld_w; a.Nn = 3 * HD;
+    a.h_out = (bf16*)h_out; a.ld_ho = ld_ho;
+    a.out_n = qkv; a.ld_on = ld_qkv;
+    a.B = B; a.zero_words = zero_words; a.n_zero = zero_words != nullptr ? n_zero : 0;
+    const dim3 grid(NGRP * ((B + 15) / 16));
+    COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_HEAD>), grid, dim3(256), 0, stream, a);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -334,7 +334,8 @@ int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lma
  *   z1 = vec . Wo^T + h;  a = LN1(z1);  hid = relu(a . W1^T + b1);  z2 = hid . W2^T + b2 + a;  h_out = LN2(z2)
  *   (o_net + residual + LayerNorm model.py:344-352, PositionwiseFF model.py:163-179)
  * and then out_n = h_out . Wn^T: the NEXT layer's qkv_net (logits == 0: Nn = 3 HD, bf16, model.py:297-299) or the
- * tied-embedding logits (logits != 0: + bn, fp32, columns < Nn, model.py:64-73).  vec [B][HD], h / h_out [B][D] bf16;
+ * tied-embedding logits (logits != 0: + bn, fp32, columns < Nn, model.py:64-73; rows with active[row] == 0 are not
+ * written -- active may be null).  vec [B][HD], h / h_out [B][D] bf16;
  * z1 / z2 [B][D] and hid [B][DI] are dense bf16 hand-off buffers that belong to THIS layer; sync:
  * commu_decode_tail_sync_words() arrival counters that must be ZERO on entry (one set per launch of a step); *err
  * becomes non-zero when a workgroup gave up waiting (the results of that launch are then invalid).
@@ -346,8 +347,15 @@ int commu_decode_layer_tail(const void* vec, int ld_vec, const void* h, int ld_h
                             const void* W1, int ld_w1, const float* b1, const void* W2, int ld_w2, const float* b2,
                             const float* g1, const float* be1, float eps1, const float* g2, const float* be2,
                             float eps2, int d_ln, const void* Wn, int ld_wn, int Nn, const float* bn, int logits,
-                            void* z1, void* hid, void* z2, void* h_out, int ld_ho, void* out_n, int ld_on, int B,
-                            int D, int DI, int HD, unsigned* sync, unsigned* err, hipStream_t stream);
+                            const unsigned char* active, void* z1, void* hid, void* z2, void* h_out, int ld_ho,
+                            void* out_n, int ld_on, int B, int D, int DI, int HD, unsigned* sync, unsigned* err,
+                            hipStream_t stream);
+/* First launch of a decode step on the same workgroup layout: h_out = E[tok] * scale (word embedding, model.py:409-420;
+ * fp32 table [V][d_true], ids outside [0, V) give NaN rows) and qkv = h_out . Wqkv^T (layer 0's qkv_net); also clears
+ * zero_words[0 .. n_zero) -- the arrival counters of the step's commu_decode_layer_tail launches. */
+int commu_decode_head(const int64_t* tok, const float* E, int d_true, int V, float scale, const void* Wqkv, int ld_w,
+                      void* h_out, int ld_ho, void* qkv, int ld_qkv, int B, int D, int DI, int HD,
+                      unsigned* zero_words, int n_zero, hipStream_t stream);
 
 /* ---- device-resident chord / bar forcing of the decode loop (InferenceTask.generate_sequence +
  * TeacherForceTask, commu/midi_generator/midi_inferrer.py:239-320, :16-144): per-sequence state records of
@@ -369,6 +377,15 @@ int commu_forcing_pre(int* state, int* seq, int ld_seq, const int* chord_tok, co
 int commu_forcing_post(int* state, int* seq, int ld_seq, const int* chord_pos, int ld_chord, unsigned char* wrong,
                        const unsigned char* draw, const int* token, int* live, int* klen, const unsigned char* keep,
                        int lmax, int B, hipStream_t stream);
+/* The three per-sequence stages that follow the model step as ONE launch, in this order and with the meaning of the
+ * separate entry points: commu_sample_topk (active = draw, wrong [B][729]) -> commu_forcing_post (live = null) ->
+ * commu_forcing_pre (the decision of the NEXT iteration). */
+int commu_decode_sample_post_pre(float* logits, int ld, int V, unsigned char* wrong, float temperature, int top_k,
+                                 int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
+                                 const int* chord_tok, const int* chord_pos, int ld_chord, const float* utable, int ld_u,
+                                 int max_iters, long long* tok, unsigned char* active, unsigned char* keep,
+                                 unsigned char* draw, float* uni, int* trace, int ld_trace, int* klen, int lmax, int B,
+                                 hipStream_t stream);
 /* dst[b][0:n] = src[b][0:n] where mask[b] != 0 */
 int commu_copy_rows_masked_f32(float* dst, int ldd, const float* src, int lds, const unsigned char* mask, int rows,
                                int n, hipStream_t stream);
