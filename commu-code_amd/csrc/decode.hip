@@ -47,7 +47,9 @@ __device__ __forceinline__ float oct_sum(float v) {
 
 // one workgroup per (b, h).  Both phases stream 16 bytes per lane: a wave instruction covers
 // 64/LPR consecutive cache rows (LPR = DH/8 lanes per row), fully coalesced.
-template <int DH>
+// UNR row-instructions per batch (measured at 1000 keys: 2 -> 33.5 us, 4 -> 28.5, 8 -> 28.8; the streaming part then runs at
+// 5.9 TB/s and the remaining 6 us are launch + the dependent first loads)
+template <int DH, int UNR = 4>
 __global__ __launch_bounds__(256) void decode_attn_kernel(
     const bf16* __restrict__ qkv, int ld_qkv, const bf16* kc, const bf16* vc,
     const bf16* __restrict__ rd, int ld_rd, const float* __restrict__ u, const float* __restrict__ vb,
@@ -88,29 +90,50 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const bf16* rb = rd + h * DH + 8 * sub;
     // ---- scores: RPW keys per wave instruction, UNR instructions' loads in flight together (the step is a single
     // pass over the cache: memory-level parallelism, not arithmetic, sets its speed)
-    constexpr int UNR = 4;
+    // Both loops are software-pipelined: the loads of batch i + 1 are issued before batch i is consumed, so a wave keeps
+    // 2 UNR row-instructions (16 KB with the distance table) in flight; the first V batch is requested before the softmax.
+    constexpr int STEP = 4 * RPW * UNR;
     float mx = -3.0e38f;
-    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW * UNR) {
-        bf16x8 kk[UNR], r8[UNR];
+    {
+        bf16x8 kk[UNR], r8[UNR], kn[UNR], rn[UNR];
+        auto issue = [&](bf16x8 (&kd)[UNR], bf16x8 (&rdst)[UNR], int j0) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int jc = min(j0 + 4 * RPW * u + rowl, n - 1);
-            kk[u] = ld_bf16x8(kb + (size_t)jc * DH);
-            r8[u] = ld_bf16x8(rb + (size_t)((n - 1) - jc) * ld_rd);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int j = j0 + 4 * RPW * u + rowl;
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kk[u][e]) + qv[e] * bf2f(r8[u][e]);
-            s = (LPR == 8) ? oct_sum(s) : (s + dpp_f<0xB1>(s)) + dpp_f<0x4E>(s + dpp_f<0xB1>(s));
-            if (j < n) {
-                if (sub == 0) sS[j] = s;
-                mx = fmaxf(mx, s);
+            for (int u = 0; u < UNR; ++u) {
+                const int jc = min(j0 + 4 * RPW * u + rowl, n - 1);
+                kd[u] = ld_bf16x8(kb + (size_t)jc * DH);
+                rdst[u] = ld_bf16x8(rb + (size_t)((n - 1) - jc) * ld_rd);
             }
+        };
+        auto consume = [&](const bf16x8 (&kd)[UNR], const bf16x8 (&rdst)[UNR], int j0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int j = j0 + 4 * RPW * u + rowl;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kd[u][e]) + qv[e] * bf2f(rdst[u][e]);
+                s = (LPR == 8) ? oct_sum(s) : (s + dpp_f<0xB1>(s)) + dpp_f<0x4E>(s + dpp_f<0xB1>(s));
+                if (j < n) {
+                    if (sub == 0) sS[j] = s;
+                    mx = fmaxf(mx, s);
+                }
+            }
+        };
+        // ping-pong (no register copies: a copy of a register that a load is still filling would wait for the load)
+        int j0 = w * RPW;
+        if (j0 < n) issue(kk, r8, j0);
+        for (; j0 < n; j0 += 2 * STEP) {
+            if (j0 + STEP < n) issue(kn, rn, j0 + STEP);
+            consume(kk, r8, j0);
+            if (j0 + 2 * STEP < n) issue(kk, r8, j0 + 2 * STEP);
+            if (j0 + STEP < n) consume(kn, rn, j0 + STEP);
         }
     }
+    bf16x8 v8[UNR], vn[UNR];
+    auto issue_v = [&](bf16x8 (&vd)[UNR], int j0) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) vd[u] = ld_bf16x8(vbp + (size_t)min(j0 + 4 * RPW * u + rowl, n - 1) * DH);
+    };
+    if (w * RPW < n) issue_v(v8, w * RPW);
     mx = wave_max(mx);
     if (lane == 0) red[w] = mx;
     __syncthreads();
@@ -127,19 +150,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
     // ---- P.V: lane accumulates 8 features of the keys it visits
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j0 = w * RPW; j0 < n; j0 += 4 * RPW * UNR) {
-        bf16x8 v8[UNR];
+    auto consume_v = [&](const bf16x8 (&vd)[UNR], int j0) {
         float p[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int j = j0 + 4 * RPW * u + rowl;
-            v8[u] = ld_bf16x8(vbp + (size_t)min(j, n - 1) * DH);
             p[u] = (j < n) ? sS[j] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += p[u] * bf2f(v8[u][e]);
+            for (int e = 0; e < 8; ++e) acc[e] += p[u] * bf2f(vd[u][e]);
+    };
+    for (int j0 = w * RPW; j0 < n; j0 += 2 * STEP) {
+        if (j0 + STEP < n) issue_v(vn, j0 + STEP);
+        consume_v(v8, j0);
+        if (j0 + 2 * STEP < n) issue_v(v8, j0 + 2 * STEP);
+        if (j0 + STEP < n) consume_v(vn, j0 + STEP);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) sO[w][rowl][8 * sub + e] = acc[e];
