@@ -103,10 +103,12 @@ PROTOTYPES = {
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
     "commu_decode_tail_supported": [c_i, c_i, c_i, c_i],
     "commu_decode_tail_sync_words": [],
-    "commu_decode_layer_tail": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_i,
-                                c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p,
-                                c_p],
-    "commu_decode_head": [c_p, c_p, c_i, c_i, c_f, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "commu_decode_tail_trace": [c_p],
+    "commu_decode_layer_tail": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_i, c_p, c_i, c_p,
+                                c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "commu_decode_head": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "commu_decode_tail_pack_bytes": [c_i, c_i],
+    "commu_decode_tail_pack": [c_p, c_i, c_i, c_i, c_p, c_p],
     "commu_forcing_state_ints": [],
     "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
@@ -116,10 +118,10 @@ PROTOTYPES = {
     "commu_pack_batch": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_p, c_p],
     "commu_hip_version": [],
 }
-_RESTYPE = {"commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
+_RESTYPE = {"commu_decode_tail_pack_bytes": C.c_longlong, "commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
             "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
 _NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
-            "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
+            "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_decode_tail_pack_bytes", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
 
 _lib = None
 

@@ -74,6 +74,8 @@ class DecodeState:
             self.t_h0 = torch.zeros(B, D, device=dev, dtype=BF16)
             self.t_sync = torch.zeros(L, nw, device=dev, dtype=torch.int32)
             self.t_err = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.t_packs = None
+            self.repack()
 
     def prefill(self, ctx: torch.Tensor):
         """ctx: int64 [T0, B] context tokens (midi_inferrer.py:186-197): fills the caches with their K/V
@@ -139,6 +141,25 @@ class DecodeState:
         return self.logits
 
 
+    def repack(self):
+        """(Re)build the packed weight copies the layer-tail launches read (commu_decode_tail_pack): call again whenever
+        the model's weights changed."""
+        if not self.tail_ok:
+            return
+        m = self.model
+
+        def pack(wt):
+            n, k = wt.shape
+            out = torch.empty(call("commu_decode_tail_pack_bytes", n, k) // 2, device=wt.device, dtype=BF16)
+            call("commu_decode_tail_pack", _p(wt), wt.stride(0), n, k, _p(out), _s())
+            return out
+        packs = []
+        for i in range(m.n_layer):
+            w = m._weights(i)
+            packs.append({k: pack(w[k]) for k in ("qkv", "o", "w1", "w2")})
+        self.t_packs = packs
+        self.t_pack_e = pack(m._emb_bf16())
+
     def _step_tail(self, tokens, active, keep, want_logits):
         """step() with one launch per layer after the attention (csrc/decode_tail.hip): embedding, layer 0's QKV Linear,
         then per layer [cached attention, layer tail]; the tail of layer i ends with layer i + 1's QKV Linear, the last
@@ -152,9 +173,9 @@ class DecodeState:
         u, vb = m._uv()
         ws = [m._weights(i) for i in range(L)]
         h = self.t_h0
-        call("commu_decode_head", _p(tokens), _p(E), E.shape[1], E.shape[0], math.sqrt(E.shape[1]), _p(ws[0]["qkv"]),
-             ws[0]["qkv"].stride(0), _p(h), D, _p(self.qkv), self.qkv.stride(0), B, D, DI, HD, _p(self.t_sync),
-             self.t_sync.numel(), _s())
+        pk = self.t_packs
+        call("commu_decode_head", _p(tokens), _p(E), E.shape[1], E.shape[0], math.sqrt(E.shape[1]), _p(pk[0]["qkv"]),
+             _p(h), D, _p(self.qkv), self.qkv.stride(0), B, D, DI, HD, _p(self.t_sync), self.t_sync.numel(), _s())
         dst = self.logits          # (the logits launch skips the rows of the sequences that did not step)
         for i in range(L):
             w, lay = ws[i], m.layers[i]
@@ -166,13 +187,12 @@ class DecodeState:
                 break
             ln1, ln2 = lay.dec_attn.layer_norm, lay.pos_ff.layer_norm
             if last:
-                wn, nn_, bn, out_n, ld_on, h_out = m._emb_bf16(), V, m.crit.out_layers[0].bias, dst, dst.stride(0), None
+                wn, nn_, bn, out_n, ld_on, h_out = self.t_pack_e, V, m.crit.out_layers[0].bias, dst, dst.stride(0), None
             else:
-                wn, nn_, bn, out_n, ld_on, h_out = ws[i + 1]["qkv"], 3 * HD, None, self.qkv, self.qkv.stride(0), self.t_h[i]
+                wn, nn_, bn, out_n, ld_on, h_out = pk[i + 1]["qkv"], 3 * HD, None, self.qkv, self.qkv.stride(0), self.t_h[i]
             call("commu_decode_layer_tail", _p(self.vec), self.vec.stride(0), _p(h), h.stride(0),
-                 _p(w["o"]), w["o"].stride(0), _p(w["w1"]), w["w1"].stride(0), _p(w["b1"]),
-                 _p(w["w2"]), w["w2"].stride(0), _p(w["b2"]), _p(ln1.weight), _p(ln1.bias), float(ln1.eps),
-                 _p(ln2.weight), _p(ln2.bias), float(ln2.eps), ln1.weight.numel(), _p(wn), wn.stride(0), nn_, _p(bn),
+                 _p(pk[i]["o"]), _p(pk[i]["w1"]), _p(w["b1"]), _p(pk[i]["w2"]), _p(w["b2"]), _p(ln1.weight), _p(ln1.bias),
+                 float(ln1.eps), _p(ln2.weight), _p(ln2.bias), float(ln2.eps), ln1.weight.numel(), _p(wn), nn_, _p(bn),
                  1 if last else 0, _p(active), _p(self.t_z1[i]), _p(self.t_hid[i]), _p(self.t_z2[i]), _p(h_out), D,
                  _p(out_n), ld_on, B, D, DI, HD, _p(self.t_sync[i]), _p(self.t_err), _s())
             h = h_out
@@ -302,6 +322,7 @@ class ForcedDecoder:
         ctx = torch.tensor([[0] + list(m[:n_cond - 1]) for m in encoded_metas], dtype=torch.long).t().contiguous()
         self.state.kc.zero_()
         self.state.vc.zero_()
+        self.state.repack()          # (the model may have been trained since the decoder was built)
         self.state.prefill(ctx.to(self.dev))
         fsm = np.zeros((B, self.NF), dtype=np.int32)
         seq = np.zeros((B, self.ld_seq), dtype=np.int32)

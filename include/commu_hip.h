@@ -342,18 +342,27 @@ int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lma
  * commu_decode_tail_supported(B, D, DI, HD) names the shapes this build takes (others: -22; callers use the
  * per-Linear launches).  d_ln: LayerNorm width (<= D; zero-padded models). */
 int commu_decode_tail_supported(int B, int D, int DI, int HD);
+/* diagnostics: following layer-tail / head launches write 100 MHz timestamps of their phase boundaries to
+ * buf[workgroup][16] (device memory, 128 x 16 words; null: off) */
+int commu_decode_tail_trace(unsigned long long* buf);
 int commu_decode_tail_sync_words(void);
-int commu_decode_layer_tail(const void* vec, int ld_vec, const void* h, int ld_h, const void* Wo, int ld_wo,
-                            const void* W1, int ld_w1, const float* b1, const void* W2, int ld_w2, const float* b2,
-                            const float* g1, const float* be1, float eps1, const float* g2, const float* be2,
-                            float eps2, int d_ln, const void* Wn, int ld_wn, int Nn, const float* bn, int logits,
+int commu_decode_layer_tail(const void* vec, int ld_vec, const void* h, int ld_h, const void* Wo_packed,
+                            const void* W1_packed, const float* b1, const void* W2_packed, const float* b2,
+                            const float* g1, const float* be1, float eps1, const float* g2, const float* be2, float eps2,
+                            int d_ln, const void* Wn_packed, int Nn, const float* bn, int logits,
                             const unsigned char* active, void* z1, void* hid, void* z2, void* h_out, int ld_ho,
                             void* out_n, int ld_on, int B, int D, int DI, int HD, unsigned* sync, unsigned* err,
                             hipStream_t stream);
+/* The four weights of a layer tail (and the head's) are read from PACKED copies: the fragments of one workgroup and
+ * wave are consecutive, so every wave instruction reads 1 KB of consecutive bytes.  commu_decode_tail_pack writes the
+ * packed copy of a bf16 [N][K] weight (row stride ldw, K % 128 == 0; rows >= N of the last tiles are zero) into `out`
+ * (commu_decode_tail_pack_bytes(N, K) bytes); it must be repeated whenever the weight changes. */
+long long commu_decode_tail_pack_bytes(int N, int K);
+int commu_decode_tail_pack(const void* W, int ldw, int N, int K, void* out, hipStream_t stream);
 /* First launch of a decode step on the same workgroup layout: h_out = E[tok] * scale (word embedding, model.py:409-420;
  * fp32 table [V][d_true], ids outside [0, V) give NaN rows) and qkv = h_out . Wqkv^T (layer 0's qkv_net); also clears
  * zero_words[0 .. n_zero) -- the arrival counters of the step's commu_decode_layer_tail launches. */
-int commu_decode_head(const int64_t* tok, const float* E, int d_true, int V, float scale, const void* Wqkv, int ld_w,
+int commu_decode_head(const int64_t* tok, const float* E, int d_true, int V, float scale, const void* Wqkv_packed,
                       void* h_out, int ld_ho, void* qkv, int ld_qkv, int B, int D, int DI, int HD,
                       unsigned* zero_words, int n_zero, hipStream_t stream);
 
