@@ -104,6 +104,7 @@ PROTOTYPES = {
     "commu_decode_tail_supported": [c_i, c_i, c_i, c_i],
     "commu_decode_tail_sync_words": [],
     "commu_decode_tail_trace": [c_p],
+    "commu_decode_loop_trace": [c_p],
     "commu_decode_layer_tail": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_i, c_p, c_i, c_p,
                                 c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "commu_decode_head": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],

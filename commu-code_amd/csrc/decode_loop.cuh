@@ -5,6 +5,45 @@
 
 namespace {
 
+// Wave-wide reductions and scans without LDS traffic: DPP inside the rows of 16 lanes, v_readlane across the four rows
+// (a __shfl_* is a ds_bpermute_b32 + wait, ~130 cycles each; the sampling step made 54 of them in a row: 3 us).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ float lane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wsum_f(float v) {          // uniform result
+    v = row16_sum(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
+}
+__device__ __forceinline__ float wmax_f(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
+}
+__device__ __forceinline__ int wmin_i(int v) {
+    v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wmax_i(int v) {
+    v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v)); v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// inclusive prefix sums in lane order: row_shr 1, 2, 4, 8 (lanes without a source add 0), then the totals of the rows before
+__device__ __forceinline__ float wscan_f(float v, int lane) {
+    v += dpp_f<0x111>(v); v += dpp_f<0x112>(v); v += dpp_f<0x114>(v); v += dpp_f<0x118>(v);
+    const float t0 = lane_f(v, 15), t1 = lane_f(v, 31), t2 = lane_f(v, 47);
+    const int r = lane >> 4;
+    return v + ((r >= 1 ? t0 : 0.f) + (r >= 2 ? t1 : 0.f) + (r >= 3 ? t2 : 0.f));
+}
+__device__ __forceinline__ int wscan_i(int v, int lane) {
+    v += dpp_i<0x111>(v); v += dpp_i<0x112>(v); v += dpp_i<0x114>(v); v += dpp_i<0x118>(v);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int r = lane >> 4;
+    return v + (r >= 1 ? t0 : 0) + (r >= 2 ? t1 : 0) + (r >= 3 ? t2 : 0);
+}
+
 // ------------------------------------------------------------------------------------------------ sampling step (K15)
 constexpr int PER_LANE = 12;      // 64 * 12 = 768 >= 729: lane l owns ids [12 l, 12 l + 12)
 
@@ -19,6 +58,20 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
     float* lg = logits + (size_t)b * ld;
     float p[PER_LANE];
     const int base = lane * PER_LANE;
+    // every load of the step up front and unconditional (clamped index): one memory round trip, not one per element
+    float raw[PER_LANE];
+#pragma unroll
+    for (int e = 0; e < PER_LANE; ++e) raw[e] = lg[min(base + e, V - 1)];
+    unsigned wmask = 0u;          // the rejected ("wrong") tokens of this lane
+    if (wrong != nullptr) {
+        unsigned char wb[PER_LANE];
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) wb[e] = wrong[(size_t)b * ldw + min(base + e, V - 1)];
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e)
+            if (base + e < V && wb[e] != 0) wmask |= 1u << e;
+    }
+    const float u = uni != nullptr ? uni[b] : 0.5f;
     // ---- calc_probs
     if (temperature == 0.f) {
         float best = -INFINITY;
@@ -26,14 +79,10 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e) {
             const int id = base + e;
-            if (id >= 1 && id < V && lg[id] > best) { best = lg[id]; bi = id; }
+            if (id >= 1 && id < V && raw[e] > best) { best = raw[e]; bi = id; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
+        const float wbest = wmax_f(best);                      // ties: the lowest id
+        bi = wmin_i(best == wbest ? bi : V);
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e) p[e] = (base + e == bi) ? 1.f : 0.f;
     } else {
@@ -41,22 +90,20 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e) {
             const int id = base + e;
-            float x = -INFINITY;
-            if (id >= 1 && id < V) {
-                x = lg[id] / temperature;
-                lg[id] = x;                     // in-place division: compounds on a redo (Q5)
-            }
+            const bool in = id >= 1 && id < V;
+            const float x = in ? raw[e] / temperature : -INFINITY;
+            if (in) lg[id] = x;                 // in-place division: compounds on a redo (Q5)
             p[e] = x;
             mx = fmaxf(mx, x);
         }
-        mx = wave_max(mx);
+        mx = wmax_f(mx);
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e) {
             p[e] = (p[e] == -INFINITY) ? 0.f : expf(p[e] - mx);
             s += p[e];
         }
-        s = wave_sum(s);
+        s = wsum_f(s);
         const float inv = 1.f / s;
 #pragma unroll
         for (int e = 0; e < PER_LANE; ++e) p[e] *= inv;
@@ -65,12 +112,7 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
     // values: the k-th largest is found by a 32-step radix select whose counts are wave ballots + scalar popcounts (no
     // cross-lane data movement, ~1 us), instead of k rounds of a wave arg-max (12 LDS / DPP exchanges each: ~19 us at
     // k = 32); elements equal to the threshold are admitted in id order until k are kept.
-    unsigned keep = 0u, wmask = 0u;          // wmask: the rejected ("wrong") tokens of this lane, read before the selection
-    if (wrong != nullptr) {
-#pragma unroll
-        for (int e = 0; e < PER_LANE; ++e)
-            if (base + e < V && wrong[(size_t)b * ldw + base + e] != 0) wmask |= 1u << e;
-    }
+    unsigned keep = 0u;
     {
         unsigned key[PER_LANE];
 #pragma unroll
@@ -90,12 +132,7 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
             neq_lane += (key[e] == thr && base + e < V) ? 1 : 0;
         }
         // exclusive prefix of the per-lane tie counts in lane (= id) order
-        int incl = neq_lane;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
+        const int incl = wscan_i(neq_lane, lane);
         int rank = incl - neq_lane;
         const int room = top_k - ngt;          // ties admitted
 #pragma unroll
@@ -115,7 +152,7 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
         p[e] = k ? p[e] : 0.f;
         s += p[e];
     }
-    const float tot = wave_sum(s);
+    const float tot = wsum_f(s);
     if (!(tot > 0.f)) {                          // NaN / zero mass: the reference's multinomial raises
         if (lane == 0) token[b] = -1;
         if (probs_out != nullptr)
@@ -131,14 +168,8 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
         for (int e = 0; e < PER_LANE; ++e)
             if (base + e < V) probs_out[(size_t)b * ldp + base + e] = p[e];
     // ---- infer_token: smallest id with cdf[id] > u
-    float incl = ls;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
+    const float incl = wscan_f(ls, lane);
     const float excl = incl - ls;
-    const float u = uni != nullptr ? uni[b] : 0.5f;
     int cand = 1 << 30;
     float c = excl;
 #pragma unroll
@@ -151,11 +182,8 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
 #pragma unroll
     for (int e = 0; e < PER_LANE; ++e)
         if (p[e] > 0.f) last = base + e;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        cand = min(cand, __shfl_xor(cand, o, 64));
-        last = max(last, __shfl_xor(last, o, 64));
-    }
+    cand = wmin_i(cand);
+    last = wmax_i(last);
     if (lane == 0) token[b] = (cand == (1 << 30)) ? last : cand;
 }
 
@@ -255,7 +283,7 @@ __device__ __forceinline__ void forcing_pre_body(int b, int lane, int* st, int* 
         keep[b] = (unsigned char)kp;
         draw[b] = (unsigned char)dr;
     }
-    clear = __shfl(clear, 0, 64);
+    clear = __builtin_amdgcn_readfirstlane(clear);
     if (clear)
         for (int i = lane; i < VOCAB; i += 64) wrong[(size_t)b * VOCAB + i] = 0;
 }
@@ -299,7 +327,7 @@ __device__ __forceinline__ void forcing_post_body(int b, int lane, int* st, int*
         }
         if (live != nullptr && !s[F_DONE]) atomicAdd(live, 1);
     }
-    clear = __shfl(clear, 0, 64);
+    clear = __builtin_amdgcn_readfirstlane(clear);
     if (clear)
         for (int i = lane; i < VOCAB; i += 64) wrong[(size_t)b * VOCAB + i] = 0;
 }

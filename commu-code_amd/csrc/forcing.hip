@@ -50,19 +50,24 @@ struct LoopStageArgs {
     long long* tok;
     unsigned char *active, *keep, *draw;
     float* uni;
-    int* trace; int ld_trace;
+    int* step_trace; int ld_trace;
     int* klen; int lmax;
+    unsigned long long* trace;      // (diagnostics) [sequence][4] 100 MHz timestamps: start, sampled, post done, pre done
 };
 __global__ __launch_bounds__(64) void sample_post_pre_kernel(LoopStageArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 0] = wall_clock64();
     sample_topk_body(b, lane, a.logits, a.ld, a.V, a.wrong, VOCAB, a.uni, a.draw, a.temperature, a.top_k, a.token,
                      a.probs_out, a.ldp);
     __syncthreads();
+    if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 1] = wall_clock64();
     forcing_post_body(b, lane, a.st, a.seq, a.ld_seq, a.chord_pos, a.ld_chord, a.wrong, a.draw, a.token, nullptr, a.klen,
                       a.keep, a.lmax);
     __syncthreads();
+    if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 2] = wall_clock64();
     forcing_pre_body(b, lane, a.st, a.seq, a.ld_seq, a.chord_tok, a.chord_pos, a.ld_chord, a.wrong, a.utable, a.ld_u,
-                     a.max_iters, a.tok, a.active, a.keep, a.draw, a.uni, a.trace, a.ld_trace);
+                     a.max_iters, a.tok, a.active, a.keep, a.draw, a.uni, a.step_trace, a.ld_trace);
+    if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 3] = wall_clock64();
 }
 
 // dst[b][0:n] = src[b][0:n] for rows with mask[b] != 0 (the logits of the sequences that stepped: the others keep
@@ -108,6 +113,13 @@ extern "C" int commu_copy_rows_masked_f32(float* dst, int ldd, const float* src,
     return 0;
 }
 
+static unsigned long long* g_loop_trace = nullptr;
+/* diagnostics: following commu_decode_sample_post_pre launches write buf[sequence][4] timestamps (null: off) */
+extern "C" int commu_decode_loop_trace(unsigned long long* buf) {
+    g_loop_trace = buf;
+    return 0;
+}
+
 extern "C" int commu_decode_sample_post_pre(float* logits, int ld, int V, unsigned char* wrong, float temperature, int top_k,
                                             int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
                                             const int* chord_tok, const int* chord_pos, int ld_chord, const float* utable,
@@ -117,7 +129,7 @@ extern "C" int commu_decode_sample_post_pre(float* logits, int ld, int V, unsign
     if (B <= 0) return 0;
     if (V != VOCAB || V > 64 * PER_LANE || top_k < 1 || top_k > V || ld_seq < 2 || ld_chord < 1 || ld_u < 1) return -22;
     LoopStageArgs a{logits, ld, V, wrong, temperature, top_k, token, probs_out, ldp, state, seq, ld_seq, chord_tok, chord_pos,
-                    ld_chord, utable, ld_u, max_iters, tok, active, keep, draw, uni, trace, ld_trace, klen, lmax};
+                    ld_chord, utable, ld_u, max_iters, tok, active, keep, draw, uni, trace, ld_trace, klen, lmax, g_loop_trace};
     COMMU_LAUNCH(sample_post_pre_kernel, dim3(B), dim3(64), 0, stream, a);
     COMMU_LAUNCH_CHECK();
     return 0;

@@ -389,6 +389,9 @@ int commu_forcing_post(int* state, int* seq, int ld_seq, const int* chord_pos, i
 /* The three per-sequence stages that follow the model step as ONE launch, in this order and with the meaning of the
  * separate entry points: commu_sample_topk (active = draw, wrong [B][729]) -> commu_forcing_post (live = null) ->
  * commu_forcing_pre (the decision of the NEXT iteration). */
+/* diagnostics: following commu_decode_sample_post_pre launches write 100 MHz timestamps buf[sequence][4] = kernel start,
+ * after the sampling step, after post, after pre (device memory; null: off) */
+int commu_decode_loop_trace(unsigned long long* buf);
 int commu_decode_sample_post_pre(float* logits, int ld, int V, unsigned char* wrong, float temperature, int top_k,
                                  int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
                                  const int* chord_tok, const int* chord_pos, int ld_chord, const float* utable, int ld_u,
