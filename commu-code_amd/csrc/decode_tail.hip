@@ -161,7 +161,7 @@ __device__ __forceinline__ void layer_norm(bf16x8 (&xf)[KS], const float (&gm)[K
 }
 
 template <int KS, int NT>
-__device__ __forceinline__ void multiply(const bf16x8 (&wf)[NT][KS], const bf16x8 (&xf)[KS], float (*red)[12][64], int w,
+__device__ __forceinline__ void multiply(const bf16x8 (&wf)[NT][KS], const bf16x8 (&xf)[KS], float (*red)[16][64], int w,
                                          int lane) {
     f32x4 acc[NT];
 #pragma unroll
@@ -178,7 +178,7 @@ __device__ __forceinline__ void multiply(const bf16x8 (&wf)[NT][KS], const bf16x
     __syncthreads();
 }
 
-__device__ __forceinline__ f32x4 tile_sum(float (*red)[12][64], int t, int lane) {
+__device__ __forceinline__ f32x4 tile_sum(float (*red)[16][64], int t, int lane) {
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = red[0][4 * t + e][lane] + red[1][4 * t + e][lane] + red[2][4 * t + e][lane] + red[3][4 * t + e][lane];
@@ -217,9 +217,9 @@ template <int D, int DI, int HD, int MODE>
 __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
     constexpr bool LOGITS = MODE == MODE_LOGITS, HEAD = MODE == MODE_HEAD;
     constexpr int KS_D = D / 128, KS_DI = DI / 128, KS_HD = HD / 128;        // 32-wide MFMA steps per wave (4 waves split K)
-    constexpr int NT1 = D / 512, NT2 = DI / 512, NT3 = D / 512, NT4 = LOGITS ? 2 : (3 * HD) / 512;
-    static_assert(D % 512 == 0 && DI % 512 == 0 && HD % 512 == 0 && NT2 <= 3 && NT4 <= 3 && NT1 == 1, "shape");
-    __shared__ float red[4][12][64];
+    constexpr int NT1 = D / 512, NT2 = DI / 512, NT3 = D / 512, NT4 = LOGITS ? 2 : (3 * HD + 511) / 512;
+    static_assert(D % 512 == 0 && DI % 512 == 0 && HD % 128 == 0 && NT2 <= 4 && NT4 <= 4 && NT1 == 1, "shape");
+    __shared__ float red[4][16][64];
     __shared__ float st[4][16];
     __shared__ __attribute__((aligned(16))) bf16 abuf[16][16];
 
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
 }  // namespace
 
 extern "C" int commu_decode_tail_supported(int B, int D, int DI, int HD) {
-    return (B >= 1 && B <= 64 && D == 512 && DI == 1024 && HD == 512) ? 1 : 0;
+    return (B >= 1 && B <= 64 && D == 512 && DI == 1024 && (HD == 512 || HD == 640)) ? 1 : 0;
 }
 
 extern "C" int commu_decode_tail_sync_words(void) { return 12 * CNT_STRIDE; }
@@ -445,8 +445,13 @@ extern "C" int commu_decode_layer_tail(const void* vec, int ld_vec, const void* 
     a.out_n = out_n; a.ld_on = ld_on;
     a.B = B; a.sync = sync; a.err = err; a.active = active;
     const dim3 grid(NGRP * ((B + 15) / 16));
-    if (logits) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_LOGITS>), grid, dim3(256), 0, stream, a);
-    else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_QKV>), grid, dim3(256), 0, stream, a);
+    if (HD == 512) {
+        if (logits) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_LOGITS>), grid, dim3(256), 0, stream, a);
+        else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_QKV>), grid, dim3(256), 0, stream, a);
+    } else {          // 10 heads x 64: the released default config (d_model 500, 10 x 50) after zero padding
+        if (logits) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 640, MODE_LOGITS>), grid, dim3(256), 0, stream, a);
+        else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 640, MODE_QKV>), grid, dim3(256), 0, stream, a);
+    }
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -463,7 +468,8 @@ extern "C" int commu_decode_head(const int64_t* tok, const float* E, int d_true,
     a.out_n = qkv; a.ld_on = ld_qkv;
     a.B = B; a.zero_words = zero_words; a.n_zero = zero_words != nullptr ? n_zero : 0;
     const dim3 grid(NGRP * ((B + 15) / 16));
-    COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_HEAD>), grid, dim3(256), 0, stream, a);
+    if (HD == 512) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_HEAD>), grid, dim3(256), 0, stream, a);
+    else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 640, MODE_HEAD>), grid, dim3(256), 0, stream, a);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

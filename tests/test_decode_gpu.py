@@ -358,8 +358,10 @@ def test_cached_decode_at_long_memory_vs_oracle(shape):
     assert checked >= len(gaps) // 2
 
 
-@pytest.mark.parametrize("B,loaded", [(64, False), (64, True), (37, False), (3, True)])
-def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded):
+@pytest.mark.parametrize("B,loaded,shape", [(64, False, (6, 8, 512, 1024)), (64, True, (6, 8, 512, 1024)),
+                                            (37, False, (6, 8, 512, 1024)), (3, True, (6, 8, 512, 1024)),
+                                            (64, True, (6, 10, 500, 1000)), (5, False, (6, 10, 500, 1000))])
+def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded, shape):
     """commu_decode_layer_tail (four Linears + two LayerNorms of a layer as phases of one launch, hand-offs between
     workgroups inside the launch) against the chain of per-Linear launches it replaces, on the same model, caches and
     tokens, for 160 consecutive steps: every step's logits within bf16 rounding of each other (a stale or torn hand-off
@@ -367,7 +369,7 @@ def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded):
     keeps the GPU busy with large GEMMs meanwhile, so the workgroups of a launch start and run unevenly."""
     import commu_amd.generate as G
     from test_configs_gpu import build
-    model, cfg, s, params = build(6, 8, 512, 1024, 1, 4146, seed=23)
+    model, cfg, s, params = build(*shape, 1, 4146, seed=23)          # (the second shape: the released default, zero-padded)
     model.eval()
     model.same_length = True
     model.reset_length(1, 4146)
@@ -404,6 +406,6 @@ def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded):
     assert torch.equal(st_a.klen, st_b.klen)
     kerr = float((st_a.kc.float() - st_b.kc.float()).abs().max()) / float(st_b.kc.float().abs().max())
     verr = float((st_a.vc.float() - st_b.vc.float()).abs().max()) / float(st_b.vc.float().abs().max())
-    print(f"layer tail vs per-Linear chain, B={B}, loaded={loaded}: worst logit difference {worst:.2e} of range, "
+    print(f"layer tail vs per-Linear chain, {shape}, B={B}, loaded={loaded}: worst logit difference {worst:.2e} of range, "
           f"K cache {kerr:.2e}, V cache {verr:.2e}")
     assert kerr < 2e-2 and verr < 2e-2
