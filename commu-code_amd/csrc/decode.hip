@@ -61,33 +61,37 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     __shared__ float red[8];
     __shared__ float sO[4][RPW][DH];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    if (active != nullptr && !active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane % LPR, rowl = lane / LPR;
-    if (append) {          // fused kv_append: this head's K and V of the new token go to cache row klen[b]
-        const int pos = klen[b];
-        if (pos < Lmax && tid < 2 * LPR) {
-            const int which = tid / LPR, c = tid % LPR;          // 0: K, 1: V
-            const bf16* src = qkv + (size_t)b * ld_qkv + (1 + which) * H * DH + h * DH + 8 * c;
-            bf16* dst = (bf16*)(which ? vc : kc) + (((size_t)b * H + h) * Lmax + pos) * DH + 8 * c;
-            st_bf16x8(dst, ld_bf16x8(src));
-        }
-        __syncthreads();          // workgroup-scope release/acquire: the row is read back below by other waves
-    }
-    const int n = min(klen[b] + 1, Lmax);              // keys 0..klen[b] (the new token included)
-    float qu[8], qv[8];
-    {
-        const bf16x8 q8 = ld_bf16x8(qkv + (size_t)b * ld_qkv + h * DH + 8 * sub);
+    // one round trip for everything the step needs before the cache: length, active flag, q, the biases, and the new
+    // token's K and V (every lane: the 8 features of its chunk)
+    const int pos = klen[b];
+    const unsigned char act = active != nullptr ? active[b] : (unsigned char)1;
+    const bf16* qrow = qkv + (size_t)b * ld_qkv + h * DH + 8 * sub;
+    const bf16x8 q8 = ld_bf16x8(qrow);
+    const bf16x8 knew = ld_bf16x8(qrow + H * DH), vnew = ld_bf16x8(qrow + 2 * H * DH);
+    float ub[8], vbb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float q = bf2f(q8[e]);
-            qu[e] = (q + u[h * DH + 8 * sub + e]) * scale;
-            qv[e] = (q + vb[h * DH + 8 * sub + e]) * scale;
-        }
+    for (int e = 0; e < 8; ++e) { ub[e] = u[h * DH + 8 * sub + e]; vbb[e] = vb[h * DH + 8 * sub + e]; }
+    if (!act) return;
+    // fused kv_append: this head's K and V of the new token go to cache row klen[b]; the step itself takes them from
+    // registers (row `self`), so nothing waits for the store
+    const int self = (append && pos < Lmax) ? pos : -1;
+    if (self >= 0 && tid < 2 * LPR) {
+        bf16* dst = (bf16*)(tid < LPR ? kc : vc) + (((size_t)b * H + h) * Lmax + pos) * DH + 8 * sub;
+        st_bf16x8(dst, tid < LPR ? knew : vnew);
     }
+    const int n = min(pos + 1, Lmax);              // keys 0..klen[b] (the new token included)
     const bf16* kb = kc + ((size_t)b * H + h) * Lmax * DH + 8 * sub;
     const bf16* vbp = vc + ((size_t)b * H + h) * Lmax * DH + 8 * sub;
     const bf16* rb = rd + h * DH + 8 * sub;
+    float qu[8], qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float q = bf2f(q8[e]);
+        qu[e] = (q + ub[e]) * scale;
+        qv[e] = (q + vbb[e]) * scale;
+    }
     // ---- scores: RPW keys per wave instruction, UNR instructions' loads in flight together (the step is a single
     // pass over the cache: memory-level parallelism, not arithmetic, sets its speed)
     // Both loops are software-pipelined: the loads of batch i + 1 are issued before batch i is consumed, so a wave keeps
@@ -109,8 +113,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             for (int u = 0; u < UNR; ++u) {
                 const int j = j0 + 4 * RPW * u + rowl;
                 float s = 0.f;
+                const bf16x8 kx = (j == self) ? knew : kd[u];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kd[u][e]) + qv[e] * bf2f(rdst[u][e]);
+                for (int e = 0; e < 8; ++e) s += qu[e] * bf2f(kx[e]) + qv[e] * bf2f(rdst[u][e]);
                 s = (LPR == 8) ? oct_sum(s) : (s + dpp_f<0xB1>(s)) + dpp_f<0x4E>(s + dpp_f<0xB1>(s));
                 if (j < n) {
                     if (sub == 0) sS[j] = s;
@@ -158,9 +163,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
             p[u] = (j < n) ? sS[j] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
+        for (int u = 0; u < UNR; ++u) {
+            const bf16x8 vx = (j0 + 4 * RPW * u + rowl == self) ? vnew : vd[u];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += p[u] * bf2f(vd[u][e]);
+            for (int e = 0; e < 8; ++e) acc[e] += p[u] * bf2f(vx[e]);
+        }
     };
     for (int j0 = w * RPW; j0 < n; j0 += 2 * STEP) {
         if (j0 + STEP < n) issue_v(vn, j0 + STEP);
