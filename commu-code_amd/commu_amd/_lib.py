@@ -98,6 +98,7 @@ PROTOTYPES = {
     "commu_attn_delta": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_transpose_heads": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "commu_sample_topk": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
+    "commu_sample_topk_topp": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_f, c_p, c_p, c_i, c_p],
     "commu_decode_kv_append": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_decode_attn": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
@@ -113,7 +114,7 @@ PROTOTYPES = {
     "commu_forcing_state_ints": [],
     "commu_forcing_pre": [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "commu_forcing_post": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
-    "commu_decode_sample_post_pre": [c_p, c_i, c_i, c_p, c_f, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i,
+    "commu_decode_sample_post_pre": [c_p, c_i, c_i, c_p, c_f, c_i, c_f, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i,
                                      c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_pack_batch": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_p, c_p],

@@ -216,9 +216,10 @@ class ForcedDecoder:
     POLL = 16          # iterations between two looks at the `done` flags (one D2H of B ints)
 
     def __init__(self, model, B: int, generation_length: int, memory_length: int, temperature: float, top_k: int,
-                 max_chords: int = 64, record_trace: bool = False):
+                 max_chords: int = 64, record_trace: bool = False, top_p: float = 1.0):
         self.model, self.B = model, B
         self.generation_length, self.temperature, self.top_k = int(generation_length), float(temperature), int(top_k)
+        self.top_p = float(top_p)          # nucleus filter after top-k (extra mode; 1.0 = the reference's behaviour)
         dev = next(model.parameters()).device
         self.dev = dev
         self.NF = call("commu_forcing_state_ints")
@@ -267,7 +268,8 @@ class ForcedDecoder:
         if want_probs and self.probs is None:
             self.probs = torch.zeros(B, TOKEN_OFFSET.VOCAB_SIZE, device=self.dev)
         ops.sample_topk(self.state.logits, self.temperature, self.top_k, wrong=self.wrong, uniforms=self.uni,
-                        active=self.draw, token=self.token, probs_out=self.probs if want_probs else None)
+                        active=self.draw, token=self.token, probs_out=self.probs if want_probs else None,
+                        top_p=self.top_p)
         call("commu_forcing_post", _p(self.fsm), _p(self.seq), self.ld_seq, _p(self.chord_pos), self.ld_chord,
              _p(self.wrong), _p(self.draw), _p(self.token), None, _p(self.state.klen), _p(self.keep), self.state.Lmax,
              B, _s())
@@ -278,7 +280,7 @@ class ForcedDecoder:
         st = self.state
         st.step(self.tok, self.active, None)
         call("commu_decode_sample_post_pre", _p(st.logits), st.logits.stride(0), TOKEN_OFFSET.VOCAB_SIZE, _p(self.wrong),
-             self.temperature, self.top_k, _p(self.token), None, 0, _p(self.fsm), _p(self.seq), self.ld_seq,
+             self.temperature, self.top_k, self.top_p, _p(self.token), None, 0, _p(self.fsm), _p(self.seq), self.ld_seq,
              _p(self.chord_tok), _p(self.chord_pos), self.ld_chord, _p(self.utable), self.ld_u, self.generation_length,
              _p(self.tok), _p(self.active), _p(self.keep), _p(self.draw), _p(self.uni), _p(self.trace), self.ld_trace,
              _p(st.klen), st.Lmax, self.B, _s())
@@ -404,20 +406,21 @@ class BatchedGenerator:
         self.use_graph = True
         self._decoders = {}
 
-    def decoder(self, B, temperature, top_k, max_chords):
-        key = (B, float(temperature), int(top_k), self.trace is not None)
+    def decoder(self, B, temperature, top_k, max_chords, top_p=1.0):
+        key = (B, float(temperature), int(top_k), float(top_p), self.trace is not None)
         dec = self._decoders.get(key)
         if dec is None or dec.ld_chord < max_chords:
             dec = ForcedDecoder(self.model, B, self.generation_length, self.memory_length, temperature, top_k,
-                                max_chords=max(64, max_chords), record_trace=self.trace is not None)
+                                max_chords=max(64, max_chords), record_trace=self.trace is not None, top_p=top_p)
             self._decoders[key] = dec
         return dec
 
     @torch.no_grad()
-    def generate(self, encoded_metas: Sequence[Sequence[int]], input_datas, temperature: float, top_k: int):
+    def generate(self, encoded_metas: Sequence[Sequence[int]], input_datas, temperature: float, top_k: int,
+                 top_p: float = 1.0):
         B = len(input_datas)
         max_chords = max(len(d.chord_token_components["chord_token"]) for d in input_datas)
-        dec = self.decoder(B, temperature, top_k, max_chords)
+        dec = self.decoder(B, temperature, top_k, max_chords, top_p)
         uniforms = None
         if temperature != 0:
             srcs = self.uniform_sources or [np.random.RandomState(1000 + b).random_sample for b in range(B)]

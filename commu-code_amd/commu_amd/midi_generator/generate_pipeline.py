@@ -45,7 +45,8 @@ class TokenGenerationPipeline:
             want = data.num_generate - len(out)
             gen.uniform_sources = [np.random.RandomState(uniform_seed + 7919 * rounds + b).random_sample
                                    for b in range(want)]
-            seqs, reports = gen.generate([encoded_meta] * want, [data] * want, data.temperature, data.top_k)
+            seqs, reports = gen.generate([encoded_meta] * want, [data] * want, data.temperature, data.top_k,
+                                         top_p=getattr(data, "top_p", 1.0))
             for seq, teacher in zip(seqs, reports):
                 self.attempts += 1
                 if seq is None:

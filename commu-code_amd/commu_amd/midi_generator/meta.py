@@ -156,6 +156,10 @@ class InputData:
             setattr(self, f, kw[f])
         self.num_generate = int(kw.get("num_generate", 1))
         self.top_k = int(kw.get("top_k", 32))
+        top_p = kw.get("top_p")                              # not in the reference: nucleus filter after top-k; 1.0 = off
+        self.top_p = 1.0 if top_p is None else float(top_p)
+        if not 0.0 < self.top_p <= 1.0:
+            raise ValueError("top_p must be in (0, 1]")
         self.temperature = float(kw.get("temperature", 0.95))
         self.output_dir = kw.get("output_dir")
         nm = self.num_measures

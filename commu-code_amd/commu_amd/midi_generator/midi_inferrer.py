@@ -101,7 +101,8 @@ class InferenceTask:
             want = data.num_generate - len(out)
             gen.uniform_sources = [np.random.RandomState(self.uniform_seed + 7919 * rounds + b).random_sample
                                    for b in range(want)]
-            seqs, reports = gen.generate([list(encoded_meta)] * want, [data] * want, data.temperature, data.top_k)
+            seqs, reports = gen.generate([list(encoded_meta)] * want, [data] * want, data.temperature, data.top_k,
+                                         top_p=getattr(data, "top_p", 1.0))
             for seq, rep in zip(seqs, reports):
                 self.attempts += 1
                 if seq is None:

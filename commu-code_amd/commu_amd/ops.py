@@ -701,15 +701,17 @@ def _bias_grads(dq, du_part, du, dvb, HD, dev, defer):
         defer(bias_part)
 
 
-def sample_topk(logits, temperature, top_k, wrong=None, uniforms=None, active=None, token=None, probs_out=None):
+def sample_topk(logits, temperature, top_k, wrong=None, uniforms=None, active=None, token=None, probs_out=None,
+                top_p=1.0):
     """In-place temperature + softmax + top-k + wrong-token mask + inverse-CDF draw per sequence.
-    logits: fp32 [nseq, >=V] (row stride = ld), modified in place (logits[:, 1:V] /= temperature)."""
+    logits: fp32 [nseq, >=V] (row stride = ld), modified in place (logits[:, 1:V] /= temperature).
+    top_p < 1: nucleus filter after the top-k / rejected-token step (an extra mode; the reference has top-k only)."""
     nseq = logits.shape[0]
     V = 729
     assert logits.dtype == F32 and logits.stride(1) == 1
     if token is None:
         token = torch.empty(nseq, device=logits.device, dtype=torch.int32)
-    call("commu_sample_topk", _p(logits), logits.stride(0), nseq, V, _p(wrong), 0 if wrong is None else wrong.stride(0),
-         _p(uniforms), _p(active), float(temperature), int(top_k), _p(token), _p(probs_out),
-         0 if probs_out is None else probs_out.stride(0), _s())
+    call("commu_sample_topk_topp", _p(logits), logits.stride(0), nseq, V, _p(wrong),
+         0 if wrong is None else wrong.stride(0), _p(uniforms), _p(active), float(temperature), int(top_k), float(top_p),
+         _p(token), _p(probs_out), 0 if probs_out is None else probs_out.stride(0), _s())
     return token

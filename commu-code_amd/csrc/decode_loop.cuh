@@ -53,7 +53,7 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
                                                  const float* __restrict__ uni,
                                                  const unsigned char* __restrict__ active, float temperature,
                                                  int top_k, int* __restrict__ token, float* __restrict__ probs_out,
-                                                 int ldp) {
+                                                 int ldp, float top_p = 1.f) {
     if (active != nullptr && !active[b]) return;
     float* lg = logits + (size_t)b * ld;
     float p[PER_LANE];
@@ -164,6 +164,48 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
     float ls = 0.f;
 #pragma unroll
     for (int e = 0; e < PER_LANE; ++e) { p[e] *= inv; ls += p[e]; }
+    // ---- nucleus ("top-p") filter, an extra mode the reference does not have (top_p >= 1: off).  Applied to the
+    // distribution left by the top-k / rejected-token step: in order of decreasing probability (ties: lowest id first) a
+    // token is kept while the mass BEFORE it is < top_p; the survivors are renormalised.  The smallest kept probability
+    // v* is the largest threshold t with mass{p >= t} >= top_p: the same bitwise search as the top-k threshold, on masses.
+    if (top_p < 1.f) {
+        unsigned key[PER_LANE];
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) key[e] = (base + e < V) ? __float_as_uint(p[e]) : 0u;
+        unsigned thr = 0u;
+        for (int bit = 30; bit >= 0; --bit) {          // (p <= 1: bit 31 is never set)
+            const unsigned cand = thr | (1u << bit);
+            float m = 0.f;
+#pragma unroll
+            for (int e = 0; e < PER_LANE; ++e) m += key[e] >= cand ? p[e] : 0.f;
+            if (wsum_f(m) >= top_p) thr = cand;
+        }
+        float mg = 0.f;
+        int neq_lane = 0;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            mg += key[e] > thr ? p[e] : 0.f;
+            neq_lane += (thr != 0u && key[e] == thr) ? 1 : 0;
+        }
+        mg = wsum_f(mg);
+        const int incl_t = wscan_i(neq_lane, lane);
+        const int nties = __builtin_amdgcn_readlane(incl_t, 63);
+        int room = 0;          // ties admitted, in id order: the smallest r >= 1 with mg + r v* >= top_p
+        if (thr != 0u) room = max(1, min(nties, (int)ceilf((top_p - mg) / __uint_as_float(thr))));
+        int rank = incl_t - neq_lane;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) {
+            bool k = key[e] > thr;
+            if (thr != 0u && key[e] == thr) { k = rank < room; ++rank; }
+            p[e] = k ? p[e] : 0.f;
+            s2 += p[e];
+        }
+        const float inv2 = 1.f / wsum_f(s2);
+        ls = 0.f;
+#pragma unroll
+        for (int e = 0; e < PER_LANE; ++e) { p[e] *= inv2; ls += p[e]; }
+    }
     if (probs_out != nullptr)
         for (int e = 0; e < PER_LANE; ++e)
             if (base + e < V) probs_out[(size_t)b * ldp + base + e] = p[e];

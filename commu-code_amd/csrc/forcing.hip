@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void forcing_post_kernel(int* st, int* seq, int
 struct LoopStageArgs {
     float* logits; int ld, V;
     unsigned char* wrong;
-    float temperature; int top_k;
+    float temperature; int top_k; float top_p;
     int* token; float* probs_out; int ldp;
     int *st, *seq; int ld_seq;
     const int *chord_tok, *chord_pos; int ld_chord;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void sample_post_pre_kernel(LoopStageArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 0] = wall_clock64();
     sample_topk_body(b, lane, a.logits, a.ld, a.V, a.wrong, VOCAB, a.uni, a.draw, a.temperature, a.top_k, a.token,
-                     a.probs_out, a.ldp);
+                     a.probs_out, a.ldp, a.top_p);
     __syncthreads();
     if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 1] = wall_clock64();
     forcing_post_body(b, lane, a.st, a.seq, a.ld_seq, a.chord_pos, a.ld_chord, a.wrong, a.draw, a.token, nullptr, a.klen,
@@ -121,14 +121,14 @@ extern "C" int commu_decode_loop_trace(unsigned long long* buf) {
 }
 
 extern "C" int commu_decode_sample_post_pre(float* logits, int ld, int V, unsigned char* wrong, float temperature, int top_k,
-                                            int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
+                                            float top_p, int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
                                             const int* chord_tok, const int* chord_pos, int ld_chord, const float* utable,
                                             int ld_u, int max_iters, long long* tok, unsigned char* active,
                                             unsigned char* keep, unsigned char* draw, float* uni, int* trace, int ld_trace,
                                             int* klen, int lmax, int B, hipStream_t stream) {
     if (B <= 0) return 0;
-    if (V != VOCAB || V > 64 * PER_LANE || top_k < 1 || top_k > V || ld_seq < 2 || ld_chord < 1 || ld_u < 1) return -22;
-    LoopStageArgs a{logits, ld, V, wrong, temperature, top_k, token, probs_out, ldp, state, seq, ld_seq, chord_tok, chord_pos,
+    if (V != VOCAB || V > 64 * PER_LANE || top_k < 1 || top_k > V || ld_seq < 2 || ld_chord < 1 || ld_u < 1 || !(top_p > 0.f)) return -22;
+    LoopStageArgs a{logits, ld, V, wrong, temperature, top_k, top_p, token, probs_out, ldp, state, seq, ld_seq, chord_tok, chord_pos,
                     ld_chord, utable, ld_u, max_iters, tok, active, keep, draw, uni, trace, ld_trace, klen, lmax, g_loop_trace};
     COMMU_LAUNCH(sample_post_pre_kernel, dim3(B), dim3(64), 0, stream, a);
     COMMU_LAUNCH_CHECK();

@@ -17,20 +17,28 @@ __global__ __launch_bounds__(64) void sample_topk_kernel(float* __restrict__ log
                                                          const unsigned char* __restrict__ active,
                                                          float temperature, int top_k,
                                                          int* __restrict__ token, float* __restrict__ probs_out,
-                                                         int ldp) {
+                                                         int ldp, float top_p) {
     sample_topk_body(blockIdx.x, threadIdx.x, logits, ld, V, wrong, ldw, uni, active, temperature, top_k, token, probs_out,
-                     ldp);
+                     ldp, top_p);
 }
 
 }  // namespace
 
+extern "C" int commu_sample_topk_topp(float* logits, int ld, int nseq, int V, const unsigned char* wrong, int ldw,
+                                      const float* uniforms, const unsigned char* active, float temperature,
+                                      int top_k, float top_p, int* token, float* probs_out, int ldp,
+                                      hipStream_t stream) {
+    if (nseq <= 0) return 0;
+    if (V > 64 * PER_LANE || top_k < 1 || top_k > V || !(top_p > 0.f)) return -22;
+    COMMU_LAUNCH(sample_topk_kernel, dim3(nseq), dim3(64), 0, stream, logits, ld, V, wrong, ldw, uniforms,
+                 active, temperature, top_k, token, probs_out, ldp, top_p);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int commu_sample_topk(float* logits, int ld, int nseq, int V, const unsigned char* wrong, int ldw,
                                  const float* uniforms, const unsigned char* active, float temperature,
                                  int top_k, int* token, float* probs_out, int ldp, hipStream_t stream) {
-    if (nseq <= 0) return 0;
-    if (V > 64 * PER_LANE || top_k < 1 || top_k > V) return -22;
-    COMMU_LAUNCH(sample_topk_kernel, dim3(nseq), dim3(64), 0, stream, logits, ld, V, wrong, ldw, uniforms,
-                 active, temperature, top_k, token, probs_out, ldp);
-    COMMU_LAUNCH_CHECK();
-    return 0;
+    return commu_sample_topk_topp(logits, ld, nseq, V, wrong, ldw, uniforms, active, temperature, top_k, 1.f, token,
+                                  probs_out, ldp, stream);
 }

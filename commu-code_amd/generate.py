@@ -41,6 +41,8 @@ def parse_args():
     input_arg_parser.add_argument("--num_generate", type=int)
     input_arg_parser.add_argument("--top_k", type=int, default=32)
     input_arg_parser.add_argument("--temperature", type=float, default=0.95)
+    # not in the reference (top-k only, generate.py:43): nucleus filter applied after top-k; 1.0 = off
+    input_arg_parser.add_argument("--top_p", type=float, default=1.0)
     # not in the reference (which retries rejected sequences forever, midi_inferrer.py:342-353): bound the retries
     input_arg_parser.add_argument("--max_rounds", type=int, default=None)
     # not in the reference: replicas of the generator, one per GPU (default: every visible GPU, at most num_generate)

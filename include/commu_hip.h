@@ -315,6 +315,12 @@ int commu_transpose_heads(const void* src, int ld, const float* bias, void* dst,
 int commu_sample_topk(float* logits, int ld, int nseq, int V, const unsigned char* wrong, int ldw,
                       const float* uniforms, const unsigned char* active, float temperature, int top_k,
                       int* token, float* probs_out, int ldp, hipStream_t stream);
+/* the same with a nucleus ("top-p") filter after the top-k / rejected-token step -- an extra mode, the reference has none
+ * (generate.py:43-44 offers top_k and temperature only): in order of decreasing probability (ties: lowest id first) a
+ * token is kept while the probability mass before it is < top_p; survivors renormalised.  top_p >= 1: off. */
+int commu_sample_topk_topp(float* logits, int ld, int nseq, int V, const unsigned char* wrong, int ldw,
+                           const float* uniforms, const unsigned char* active, float temperature, int top_k,
+                           float top_p, int* token, float* probs_out, int ldp, hipStream_t stream);
 
 /* ---- single-token decode step with a K/V cache (forward_generate with qlen 1, model.py:606-628, as
  * called by midi_inferrer.py:199-207).  Caches are bf16 [B][H][Lmax][DH] per layer; klen[b] = valid rows
@@ -387,13 +393,13 @@ int commu_forcing_post(int* state, int* seq, int ld_seq, const int* chord_pos, i
                        const unsigned char* draw, const int* token, int* live, int* klen, const unsigned char* keep,
                        int lmax, int B, hipStream_t stream);
 /* The three per-sequence stages that follow the model step as ONE launch, in this order and with the meaning of the
- * separate entry points: commu_sample_topk (active = draw, wrong [B][729]) -> commu_forcing_post (live = null) ->
+ * separate entry points: commu_sample_topk_topp (active = draw, wrong [B][729]) -> commu_forcing_post (live = null) ->
  * commu_forcing_pre (the decision of the NEXT iteration). */
 /* diagnostics: following commu_decode_sample_post_pre launches write 100 MHz timestamps buf[sequence][4] = kernel start,
  * after the sampling step, after post, after pre (device memory; null: off) */
 int commu_decode_loop_trace(unsigned long long* buf);
 int commu_decode_sample_post_pre(float* logits, int ld, int V, unsigned char* wrong, float temperature, int top_k,
-                                 int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
+                                 float top_p, int* token, float* probs_out, int ldp, int* state, int* seq, int ld_seq,
                                  const int* chord_tok, const int* chord_pos, int ld_chord, const float* utable, int ld_u,
                                  int max_iters, long long* tok, unsigned char* active, unsigned char* keep,
                                  unsigned char* draw, float* uni, int* trace, int ld_trace, int* klen, int lmax, int B,

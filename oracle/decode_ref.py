@@ -42,6 +42,19 @@ def apply_sampling(probs: torch.Tensor, top_k: int, wrong_tokens: Sequence[int])
     return out / out.sum()
 
 
+def apply_top_p(probs: torch.Tensor, top_p: float) -> torch.Tensor:
+    """Nucleus filter of the build's extra sampling mode (the reference has top-k only): in order of decreasing
+    probability (ties: lowest id first) a token is kept while the mass before it is < top_p; renormalised."""
+    if top_p >= 1.0:
+        return probs
+    srt, idx = torch.sort(probs.double(), descending=True, stable=True)
+    before = torch.cumsum(srt, 0) - srt
+    keep = torch.zeros_like(probs)
+    keep[idx[(before < top_p) & (srt > 0)]] = 1.0
+    out = probs * keep
+    return out / out.sum()
+
+
 def draw_inverse_cdf(probs: torch.Tensor, u: float) -> int:
     """Draw with an injected uniform variate: smallest t with cumsum(p)[t] > u.
     (torch.multinomial's RNG stream, midi_inferrer.py:234-237, is not reproducible on a

@@ -71,6 +71,49 @@ def test_sampling_topk_selection_matches_torch_topk():
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("top_p", [0.3, 0.6, 0.9, 0.999])
+def test_sampling_nucleus_filter_vs_oracle(top_p):
+    """The extra top-p mode (commu_sample_topk_topp; the reference has top-k only): the kept set and the renormalised
+    probabilities against oracle.decode_ref.apply_top_p applied to the oracle's top-k / rejected-token distribution, with
+    and without rejected tokens, including rows with exact ties at the nucleus boundary; the draw is the inverse CDF of
+    that distribution.  Rows whose cumulative mass passes within 1e-5 of top_p are checked up to that one token."""
+    from commu_amd import ops
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(64, 729, generator=g) * 2.5
+    logits[0, 10:40] = 6.0                                   # a plateau of equal probabilities: ties at the boundary
+    logits[1, 100:103] = 7.0
+    wrong = torch.zeros(64, 729, dtype=torch.uint8)
+    wrong[::3, 7] = 1
+    wrong[5, logits[5, 1:].argmax() + 1] = 1
+    us = torch.rand(64, generator=g)
+    for use_wrong in (False, True):
+        pr = torch.zeros(64, 729, device=DEV)
+        tok = ops.sample_topk(logits.clone().to(DEV), 0.95, 32, wrong=wrong.to(DEV) if use_wrong else None,
+                              uniforms=us.to(DEV), probs_out=pr, top_p=top_p).cpu()
+        pr = pr.cpu()
+        for b in range(64):
+            wl = [int(i) for i in wrong[b].nonzero().flatten()] if use_wrong else []
+            base = Dz.apply_sampling(Dz.calc_probs(logits[b, 1:].clone(), 0.95), 32, wl)
+            ref = Dz.apply_top_p(base, top_p)
+            srt = torch.sort(base.double(), descending=True, stable=True).values
+            before = torch.cumsum(srt, 0) - srt
+            near = bool(((before - top_p).abs() < 1e-5).any())          # the boundary falls on a rounding
+            same_set = torch.equal(pr[b] > 0, ref > 0)
+            assert same_set or (near and int(((pr[b] > 0) != (ref > 0)).sum()) == 1), (b, use_wrong)
+            if same_set:
+                assert float((pr[b] - ref).abs().max()) < 2e-6, (b, use_wrong)
+                assert abs(float(pr[b].sum()) - 1.0) < 1e-5
+                want = Dz.draw_inverse_cdf(ref, float(us[b]))
+                if int(tok[b]) != want:
+                    cdf = torch.cumsum(ref.double(), 0)
+                    assert float((cdf - float(us[b])).abs().min()) < 1e-5
+    # top_p = 1 is the reference's step, bit for bit
+    a, b_ = torch.zeros(64, 729, device=DEV), torch.zeros(64, 729, device=DEV)
+    ops.sample_topk(logits.clone().to(DEV), 0.95, 32, uniforms=us.to(DEV), probs_out=a)
+    ops.sample_topk(logits.clone().to(DEV), 0.95, 32, uniforms=us.to(DEV), probs_out=b_, top_p=1.0)
+    assert torch.equal(a, b_)
+
+
 def test_sampling_draw_is_inverse_cdf():
     from commu_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -125,12 +168,12 @@ def _data(z, tag):
         "chord_token": z[f"{tag}_chord_token"].tolist(), "chord_position": z[f"{tag}_chord_position"].tolist()})
 
 
-def _decoder(model, z, tags, record_trace=True):
+def _decoder(model, z, tags, record_trace=True, top_p=1.0):
     """A ForcedDecoder loaded with one sequence per fixture tag (same temperature / top-k / bias)."""
     from commu_amd.generate import ForcedDecoder
     temp, _, top_k, _ = z[f"{tags[0]}_cfg"]
     glen = max(int(z[f"{t}_cfg"][3]) for t in tags)
-    dec = ForcedDecoder(model, len(tags), glen, 4146, float(temp), int(top_k), record_trace=record_trace)
+    dec = ForcedDecoder(model, len(tags), glen, 4146, float(temp), int(top_k), record_trace=record_trace, top_p=top_p)
     uni = np.full((len(tags), dec.ld_u), 0.5, dtype=np.float32)
     for b, t in enumerate(tags):
         u = z[f"{t}_uniforms"]
@@ -261,6 +304,36 @@ def test_sampled_hipgraph_matches_eager_and_margin_fixture(golden_dir):
     ref_trace = [tuple(t) for t in z["sample8m_trace"].tolist()]
     for b in range(16):
         assert outs[0][0][b] == ref and outs[0][1][b] == ref_trace
+
+
+def test_nucleus_mode_in_the_decode_loop(golden_dir):
+    """top_p < 1 through the whole loop (the fused sampling / forcing launch inside the graph): replay equals eager
+    execution, the sequences differ from the top-k-only run of the same variates (the filter is active), and every drawn
+    token lies inside the nucleus of its step's distribution (checked with the per-stage launches on the first draws)."""
+    z = load(golden_dir, "g6_decode.npz")
+    model = _build(golden_dir, z, z["sample8m_bias"])
+    tags = ["sample8m"] * 8
+    outs = []
+    for use_graph in (True, False):
+        dec = _decoder(model, z, tags, top_p=0.5)
+        with torch.no_grad():
+            dec.run(use_graph=use_graph)
+        outs.append(dec.sequences())
+    assert outs[0] == outs[1]
+    assert outs[0][0][0] != z["sample8m_seq"].tolist()
+    dec = _decoder(model, z, tags, top_p=0.5)
+    with torch.no_grad():
+        for _ in range(24):
+            dec.iteration(want_probs=True)
+            torch.cuda.synchronize()
+            drew, tok, pr = dec.draw.cpu(), dec.token.cpu(), dec.probs.cpu()
+            for b in range(8):
+                if drew[b] and tok[b] >= 0:
+                    srt = torch.sort(pr[b].double(), descending=True).values
+                    assert pr[b, tok[b]] > 0 and float(srt[srt > 0].sum()) > 0.999
+                    # the kept set is a nucleus: dropping its least likely member leaves less than top_p of the ORIGINAL
+                    # mass -- equivalently the kept set has at most as many members as the top-k set
+                    assert int((pr[b] > 0).sum()) <= 32
 
 
 def test_decoder_refuses_a_generation_longer_than_its_memory(golden_dir):

@@ -293,3 +293,17 @@ def test_unsupported_shapes_raise_with_the_supported_list(over, frag):
     with pytest.raises(CommuHipError) as e:
         MemTransformerLM(cfg, BaseVocab())
     assert frag in str(e.value) and "unsupported shape" in str(e.value)
+
+
+def test_oracle_nucleus_filter_known_answers():
+    """oracle.decode_ref.apply_top_p (the build's extra sampling mode): a token is kept while the mass before it, in order of
+    decreasing probability with ties in id order, is < top_p."""
+    import torch
+    from oracle import decode_ref as Dz
+    p = torch.tensor([0.05, 0.4, 0.1, 0.25, 0.2])
+    assert Dz.apply_top_p(p, 1.0) is p
+    assert torch.allclose(Dz.apply_top_p(p, 0.39), torch.tensor([0.0, 1.0, 0.0, 0.0, 0.0]))
+    assert torch.allclose(Dz.apply_top_p(p, 0.5), torch.tensor([0.0, 0.4, 0.0, 0.25, 0.0]) / 0.65)
+    assert torch.allclose(Dz.apply_top_p(p, 0.9), torch.tensor([0.0, 0.4, 0.1, 0.25, 0.2]) / 0.95)
+    t = torch.tensor([0.2, 0.2, 0.2, 0.2, 0.2])                     # ties: lowest id first
+    assert torch.allclose(Dz.apply_top_p(t, 0.5), torch.tensor([1.0, 1.0, 1.0, 0.0, 0.0]) / 3)
