@@ -195,7 +195,7 @@ def pmc_traffic(kernel, args):
     MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both in KiB -> bytes).  None when no profile matches BOTH the
     shape and the hash of the current kernel sources (a stale number is refused, not reported)."""
     import glob
-    shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // args.batch_chunk]
+    shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // passes_of(args)]
     try:
         sha = kernel_source_hash()
     except OSError:
@@ -209,6 +209,17 @@ def pmc_traffic(kernel, args):
         if rec.get("shape") == shape and rec.get("source_sha256") == sha:
             return rec.get("bytes_per_launch", {}).get(kernel)
     return None
+
+
+def passes_of(args):
+    """Forward / backward passes per optimiser step: `batch_chunk`, or 1 when the Trainer folds the micro-batches into one
+    pass (Trainer(merge_chunks=...): automatic up to Trainer.MERGE_MAX_ROWS tokens per step)."""
+    from commu_amd.train import Trainer
+    chunk = args.batch_chunk
+    merge = getattr(args, "merge_chunks", None)
+    if merge is None:
+        merge = args.tgt_len * args.batch_per_gpu <= Trainer.MERGE_MAX_ROWS
+    return 1 if (merge and 1 < chunk <= 16 and args.batch_per_gpu % chunk == 0) else chunk
 
 
 def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
@@ -235,8 +246,9 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
         reducer.broadcast_params(model)
     use_graph = getattr(args, "graph", None)
     if use_graph is None:
-        use_graph = (B // args.batch_chunk) * args.tgt_len <= 16384
-    trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer, graph=use_graph)
+        use_graph = (B // passes_of(args)) * args.tgt_len <= 16384
+    trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer, graph=use_graph,
+                      merge_chunks=getattr(args, "merge_chunks", None))
     batches = [synthetic_batch(args.tgt_len, B, dev, seed=cfg.TRAIN.seed + 1000 * rank + i, reset_prob=reset_prob)
                for i in range(4)]
     tokens_per_step = sum(b[3] for b in batches) // len(batches)
@@ -287,7 +299,7 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
       key-stationary backward 3 (dP, dV, dK: it re-reads the probabilities the query-stationary kernel stored; the
       d_head-32 variant, which recomputes QK^T and QR^T, is not on the bench path)."""
     T, M = args.tgt_len, args.mem_len
-    mb_tokens = tokens_per_step // args.batch_chunk
+    mb_tokens = tokens_per_step // passes_of(args)
     kbar = M + (T + 1) / 2.0
     products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 3.0}
     tot = {k: sum(v) for k, v in prof.items() if ":" not in k}
@@ -413,7 +425,8 @@ def extra_rows(args, dev):
         elapsed, tps, prof, pscale = train_bench(a, dev, 1, 0, steps, warmup)
         f = 3.0 * fwd_flops_per_token(a.layers, a.d_model, a.d_inner, a.tgt_len, a.mem_len) * tps
         rows[tag] = {"value": round(tps * steps / elapsed, 1), "unit": "tokens/s", "ms_per_step": round(1e3 * elapsed / steps, 3),
-                     "steps": steps, "warmup": warmup, "tokens_per_step": tps,
+                     "steps": steps, "warmup": warmup, "tokens_per_step": tps, "batch_chunk": a.batch_chunk,
+                     "passes_per_step": passes_of(a),
                      "step_mfma_frac": round(f / (elapsed / steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
                      "roofline": attention_roofline(a, prof, tps, elapsed, pscale)}
         if a.mem_len > 0 and not getattr(a, "fp8_forward", False):
@@ -426,6 +439,14 @@ def extra_rows(args, dev):
             e2, tps2, _, _ = train_bench(a, dev, 1, 0, steps, warmup, reset_prob=pr)
             rows[tag]["with_resets"] = {"reset_prob": pr, "value": round(tps2 * steps / e2, 1),
                                         "ms_per_step": round(1e3 * e2 / steps, 3)}
+        if a.batch_chunk > 1 and passes_of(a) == 1:
+            # the same step as the reference's loop over micro-batches (Trainer(merge_chunks=False)), for comparison
+            a2 = argparse.Namespace(**{**vars(a), "merge_chunks": False})
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            e3, tps3, _, _ = train_bench(a2, dev, 1, 0, steps, warmup)
+            rows[tag]["micro_batch_loop"] = {"passes_per_step": a.batch_chunk, "value": round(tps3 * steps / e3, 1),
+                                             "ms_per_step": round(1e3 * e3 / steps, 3)}
     return rows
 
 
@@ -458,6 +479,9 @@ def main():
     ap.add_argument("--from-iterator", dest="from_iterator", action="store_true",
                     help="also time the step fed by ComMUDataset.get_iterator from an on-disk .npy corpus (on by default "
                          "with the extra rows)")
+    ap.add_argument("--merge-chunks", dest="merge_chunks", action=argparse.BooleanOptionalAction, default=None,
+                    help="run the batch_chunk micro-batches of a step as one pass with per-micro-batch loss weights "
+                         "(default: automatic, up to 65536 tokens per step); --no-merge-chunks: the reference's loop")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="weight-gradient work on the main stream (default: a side stream)")
     args = ap.parse_args()
@@ -496,10 +520,11 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"transformer-xl train step L{L} D{D} H{H} DI{DI} tgt_len{T} mem_len{M} vocab729",
-                   "global_batch": B * world, "batch_per_gpu": B, "batch_chunk": args.batch_chunk, "seq_len": T,
+                   "global_batch": B * world, "batch_per_gpu": B, "batch_chunk": args.batch_chunk,
+                   "passes_per_step": passes_of(args), "seq_len": T,
                    "dropout": args.dropout, "parallelism": f"dp{world}", "optimizer": "clip1.0+Adam+invsqrt-LR",
                    "launch": ("hipGraph replay (every 4th timed step eager, for the per-kernel events)"
-                              if (args.graph if args.graph is not None else (B // args.batch_chunk) * T <= 16384) else "eager"),
+                              if (args.graph if args.graph is not None else (B // passes_of(args)) * T <= 16384) else "eager"),
                    "weights": "random init (train.py:291-342)"},
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),

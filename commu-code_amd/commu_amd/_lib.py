@@ -75,6 +75,8 @@ PROTOTYPES = {
     "commu_ce_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "commu_masked_mean": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "commu_loss_grad": [c_p, c_i, c_i, c_p, c_f, c_p, c_p],
+    "commu_masked_mean_groups": [c_p, c_p, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "commu_loss_grad_groups": [c_p, c_i, c_i, c_p, c_f, c_i, c_i, c_p, c_p],
     "commu_grad_norm": [c_p, c_z, c_p, c_i, c_p, c_p],
     "commu_adam_step": [c_p, c_p, c_p, c_p, c_p, c_z, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_p],
     "commu_adam_step_dev": [c_p, c_p, c_p, c_p, c_p, c_z, c_p, c_f, c_f, c_f, c_p, c_f, c_p],

@@ -450,6 +450,18 @@ def loss_grad(target, pad, ws_cnt, scale, g):
     return g
 
 
+def masked_mean_groups(nll, target, pad, scale, B, Bc, ws_sum, ws_cnt, out, sum_all=None):
+    """[T, B] loss whose columns are B / Bc micro-batches: out = scale * sum over the groups of their masked means."""
+    call("commu_masked_mean_groups", _p(nll), _p(target), nll.numel(), pad, scale, B, Bc, _p(ws_sum), _p(ws_cnt), _p(out),
+         _p(sum_all), _s())
+    return out
+
+
+def loss_grad_groups(target, pad, ws_cnt, scale, B, Bc, g):
+    call("commu_loss_grad_groups", _p(target), target.numel(), pad, _p(ws_cnt), scale, B, Bc, _p(g), _s())
+    return g
+
+
 def grad_norm(g, part, out):
     call("commu_grad_norm", _p(g), g.numel(), _p(part), part.numel(), _p(out), _s())
     return out

@@ -835,6 +835,46 @@ __global__ void masked_mean_final_kernel(const float* sum, const int* cnt, float
     out[0] = cnt[0] > 0 ? scale * sum[0] / (float)cnt[0] : __builtin_nanf("");
 }
 
+// Column-grouped forms: element i of a [T, B] tensor belongs to micro-batch (i % B) / Bc.  They let ONE forward / backward
+// over all B columns stand for the reference's `batch_chunk` micro-batches (train.py:136-155: each micro-batch's loss is
+// the mean over ITS non-pad targets, divided by batch_chunk): out = scale * sum_g mean_g, g[m] = scale / count_{group(m)}.
+constexpr int MAX_GROUPS = 16;
+__global__ __launch_bounds__(256) void masked_sum_groups_kernel(const float* __restrict__ nll,
+                                                                const int64_t* __restrict__ target, int n, int pad, int B,
+                                                                int Bc, int G, float* __restrict__ sum,
+                                                                int* __restrict__ cnt) {
+    __shared__ float ss[MAX_GROUPS];
+    __shared__ int sc[MAX_GROUPS];
+    if (threadIdx.x < MAX_GROUPS) { ss[threadIdx.x] = 0.f; sc[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (target[i] != pad) {
+            const int g = (i % B) / Bc;
+            atomicAdd(&ss[g], nll[i]);
+            atomicAdd(&sc[g], 1);
+        }
+    __syncthreads();
+    if (threadIdx.x < G && sc[threadIdx.x]) {
+        atomicAdd(sum + threadIdx.x, ss[threadIdx.x]);
+        atomicAdd(cnt + threadIdx.x, sc[threadIdx.x]);
+    }
+}
+__global__ void masked_mean_groups_final_kernel(const float* sum, const int* cnt, int G, float scale, float* out,
+                                                float* sum_all) {
+    float tot = 0.f, all = 0.f;
+    for (int g = 0; g < G; ++g) {
+        tot += cnt[g] > 0 ? sum[g] / (float)cnt[g] : __builtin_nanf("");          // an all-pad micro-batch: NaN, as above
+        all += sum[g];
+    }
+    out[0] = scale * tot;
+    if (sum_all != nullptr) sum_all[0] = all;
+}
+__global__ void loss_grad_groups_kernel(const int64_t* __restrict__ target, int n, int pad, const int* __restrict__ cnt,
+                                        float scale, int B, int Bc, float* __restrict__ g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] = (target[i] != pad) ? scale / (float)max(cnt[(i % B) / Bc], 1) : 0.f;
+}
+
 __global__ void copy_rows_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x)
         ((bf16x8*)dst)[i] = ((const bf16x8*)src)[i];
@@ -1125,6 +1165,32 @@ extern "C" int commu_loss_grad(const int64_t* target, int n, int pad, const int*
     if (n <= 0) return 0;
     COMMU_LAUNCH(loss_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, target, n, pad, cnt_ws,
                        scale, g);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_masked_mean_groups(const float* nll, const int64_t* target, int n, int pad, float scale, int B, int Bc,
+                                        float* sum_ws, int* cnt_ws, float* out, float* sum_all, hipStream_t stream) {
+    // out[0] = scale * sum over the B / Bc column groups of mean(nll[target != pad] within the group); sum_ws / cnt_ws:
+    // B / Bc floats / ints (kept for commu_loss_grad_groups); sum_all (optional): the sum over every non-pad target
+    if (B <= 0 || Bc <= 0 || (B % Bc) || B / Bc > MAX_GROUPS || n < 0 || (n % B)) return -22;
+    const int G = B / Bc;
+    hipMemsetAsync(sum_ws, 0, sizeof(float) * G, stream);
+    hipMemsetAsync(cnt_ws, 0, sizeof(int) * G, stream);
+    if (n > 0)
+        COMMU_LAUNCH(masked_sum_groups_kernel, dim3(cap_blocks((n + 1023) / 1024)), dim3(256), 0, stream, nll, target, n,
+                     pad, B, Bc, G, sum_ws, cnt_ws);
+    COMMU_LAUNCH(masked_mean_groups_final_kernel, dim3(1), dim3(1), 0, stream, sum_ws, cnt_ws, G, scale, out, sum_all);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int commu_loss_grad_groups(const int64_t* target, int n, int pad, const int* cnt_ws, float scale, int B, int Bc,
+                                      float* g, hipStream_t stream) {
+    if (B <= 0 || Bc <= 0 || (B % Bc) || B / Bc > MAX_GROUPS) return -22;
+    if (n <= 0) return 0;
+    COMMU_LAUNCH(loss_grad_groups_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, target, n, pad, cnt_ws, scale, B, Bc,
+                 g);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -33,6 +33,10 @@ def parse_args(argv=None):
     p.add_argument("--local_rank", type=int, default=int(os.environ.get("LOCAL_RANK", 0)))
     p.add_argument("--work_dir", type=str, required=True, help="Base directory to save the trained model.")
     # -- not in the reference: overrides of its hard-coded defaults
+    p.add_argument("--no-merge-chunks", dest="merge_chunks", action="store_false", default=None,
+                   help="(not in the reference) run the batch_chunk micro-batches one after the other like the reference; "
+                        "default: one forward / backward over all columns with per-micro-batch loss weights when the batch "
+                        "has at most 65536 tokens (same loss and gradients)")
     p.add_argument("--graph", action="store_true",
                    help="replay the optimiser step from hipGraphs once its shapes are steady (not in the reference; pays "
                         "when a micro-batch is small enough for the host's launch rate to bound the step)")
@@ -103,7 +107,8 @@ def main(argv=None):
     reducer = GradReducer() if world > 1 else None
     if reducer is not None:
         reducer.broadcast_params(model)                                         # DDP constructor semantics (C3)
-    trainer = Trainer(model, cfg, num_gpus=num_gpus, reducer=reducer, graph=bool(getattr(args, "graph", False)))
+    trainer = Trainer(model, cfg, num_gpus=num_gpus, reducer=reducer, graph=bool(getattr(args, "graph", False)),
+                      merge_chunks=getattr(args, "merge_chunks", None))
     best_val_nll = float("inf")
 
     def checkpoint(name, val_nll):                                              # train.py:29-54 (C7)

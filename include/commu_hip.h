@@ -190,6 +190,14 @@ int commu_masked_mean(const float* nll, const int64_t* target, int n, int pad, f
                       int* cnt_ws, float* out, hipStream_t stream);
 int commu_loss_grad(const int64_t* target, int n, int pad, const int* cnt_ws, float scale, float* g,
                     hipStream_t stream);
+/* Column-grouped forms for a [T][B] time-major loss whose B columns are B / Bc micro-batches of Bc columns (the reference's
+ * `batch_chunk`, train.py:136-155): out[0] = scale * sum_g mean(nll[target != pad] in group g) (scale = 1 / batch_chunk),
+ * g[m] = scale * (target[m] != pad) / count_{group of column m % B}.  One forward / backward over all columns then equals
+ * the reference's loop over micro-batches.  sum_ws / cnt_ws: B / Bc (<= 16) words; sum_all (optional): sum over all groups. */
+int commu_masked_mean_groups(const float* nll, const int64_t* target, int n, int pad, float scale, int B, int Bc,
+                             float* sum_ws, int* cnt_ws, float* out, float* sum_all, hipStream_t stream);
+int commu_loss_grad_groups(const int64_t* target, int n, int pad, const int* cnt_ws, float scale, int B, int Bc, float* g,
+                           hipStream_t stream);
 
 /* ---- optimiser (clip_grad_norm_ + optim.Adam, train.py:159-165,442) on flat fp32 buffers */
 int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out_norm, hipStream_t stream);

@@ -319,3 +319,64 @@ def test_graph_step_matches_eager_step(variant):
         if a is not None:
             assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
     assert abs(out["eager"][3][0] - out["graph"][3][0]) < 1e-4 and out["eager"][3][2] == out["graph"][3][2]
+
+
+@pytest.mark.parametrize("mem_len", [0, 64])
+def test_merged_micro_batches_match_the_reference_loop(mem_len):
+    """Trainer(merge_chunks=True) runs the `batch_chunk` micro-batches of a step (train.py:113-155) as ONE forward /
+    backward over all columns whose loss weights every token by 1 / (batch_chunk x non-pad count of ITS micro-batch).
+    Against the reference's loop (merge_chunks=False) on batches with a different number of pads in every micro-batch and
+    per-column memory resets, dropout off: the gradient of the first step (cosine, max error), the loss of four
+    consecutive steps (the XL memory carried as one tensor instead of one per micro-batch), the logging window; and the
+    loss against the oracle's loop (oracle.xl_ref.train_step with batch_chunk = 4)."""
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab
+    from commu_amd.train import Trainer, build_model
+    from oracle import xl_ref as X
+    dev = torch.device(DEV)
+    T, B, chunk = 64, 16, 4
+    cfg = get_cfg(num_layers=2, num_heads=4, units=256, inner_size=512, tgt_length=T, mem_length=mem_len, batch_size=B,
+                  batch_chunk=chunk, dropout=0.0, attention_dropout=0.0)
+    g = torch.Generator().manual_seed(77)
+    batches = []
+    for i in range(4):
+        stream = torch.randint(2, 729, (T + 1, B), generator=g)
+        data, target = stream[:-1].clone(), stream[1:].clone()
+        for c in range(chunk):                                  # pads: a different count in every micro-batch
+            cols = slice(c * (B // chunk), (c + 1) * (B // chunk))
+            npad = 5 + 11 * c + i
+            target[T - npad:, cols.start] = 0
+            data[T - npad + 1:, cols.start] = 0
+        reset = torch.rand(B, generator=g) < (0.3 if mem_len else 0.0)
+        batches.append((data.to(dev), target.to(dev), reset.to(dev), int((target != 0).sum())))
+    runs = {}
+    for merge in (True, False):
+        model = build_model(cfg, BaseVocab(), dev, seed=9)
+        model.train()
+        tr = Trainer(model, cfg, num_gpus=1, merge_chunks=merge)
+        d, t, r, n = batches[0]
+        total, _, _ = tr._device_forward_backward(d, t, r, list(tr.mems) if tr.groups else [None] * (1 if merge else chunk))
+        torch.cuda.synchronize()
+        grad = model._ensure_flat()["g"].detach().float().cpu().clone()
+        model.zero_grad()
+        assert tr.groups == (chunk if merge else 1) and len(tr.mems) == (1 if merge else chunk)
+        tr.mems = [None for _ in tr.mems]
+        losses = [float(tr.step(*b)) for b in batches]
+        runs[merge] = (float(total), grad, losses, tr.log_window())
+    (tm, gm, lm, wm), (tl, gl, ll, wl) = runs[True], runs[False]
+    assert abs(tm - tl) < 1e-3 * abs(tl), (tm, tl)
+    cos = float((gm.double() * gl.double()).sum() / (gm.double().norm() * gl.double().norm()))
+    err = float((gm - gl).abs().max()) / float(gl.abs().max())
+    print(f"merged vs loop (mem_len {mem_len}): loss {tm:.5f} / {tl:.5f}, gradient cosine {cos:.6f}, max error {err:.2e}; "
+          f"losses {lm} / {ll}")
+    assert 0.9995 < cos < 1.0 + 1e-9 and err < 2e-2, (cos, err)
+    assert all(abs(a - b) < 3e-3 * abs(b) for a, b in zip(lm, ll)), (lm, ll)
+    assert abs(wm[0] - wl[0]) < 2e-3 * abs(wl[0]) and wm[2] == wl[2]
+    # the oracle's loop over micro-batches on the first batch
+    p = {k: v.detach().float().cpu().clone() for k, v in build_model(cfg, BaseVocab(), dev, seed=9).state_dict().items()
+         if k not in ("crit.out_layers.0.weight", "pos_emb.inv_freq")}
+    s = X.XLShape(2, 4, 256, 512)
+    d, t, r, n = batches[0]
+    oloss, _, _, _ = X.train_step(p, X.adam_init(p), s, d.cpu(), t.cpu(), r.cpu(), [None] * chunk, batch_chunk=chunk,
+                                  mem_len=mem_len, same_length=False, lr_now=cfg.TRAIN.lr, clip=cfg.TRAIN.clip)
+    assert abs(tm - float(oloss)) < 2e-2, (tm, float(oloss))
