@@ -222,6 +222,13 @@ def passes_of(args):
     return 1 if (merge and 1 < chunk <= 16 and args.batch_per_gpu % chunk == 0) else chunk
 
 
+def auto_graph(args):
+    """hipGraph replay of the step pays when the step is host-bound: few tokens per pass through a small model (8 sequences
+    x 1024 tokens per GPU at L6 D512: 4.7 instead of 6.1 ms).  With large kernels it does not (cfg-5: 61.5 / 71.9 ms
+    replayed against 59.8 / 66.2 ms eager), so the default follows a work proxy: tokens per pass x layers x d_model^2."""
+    return (args.batch_per_gpu // passes_of(args)) * args.tgt_len * args.layers * args.d_model ** 2 <= 2e13
+
+
 def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     """W untimed + K timed optimiser steps of the shape in `args`; returns (elapsed seconds (max over ranks),
     tokens per step per rank, per-entry-point HIP-event times) -- None on ranks other than 0."""
@@ -246,7 +253,7 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
         reducer.broadcast_params(model)
     use_graph = getattr(args, "graph", None)
     if use_graph is None:
-        use_graph = (B // passes_of(args)) * args.tgt_len <= 16384
+        use_graph = auto_graph(args)
     trainer = Trainer(model, cfg, num_gpus=world, reducer=reducer, graph=use_graph,
                       merge_chunks=getattr(args, "merge_chunks", None))
     batches = [synthetic_batch(args.tgt_len, B, dev, seed=cfg.TRAIN.seed + 1000 * rank + i, reset_prob=reset_prob)
@@ -403,6 +410,9 @@ def gemm_roofline(prof, elapsed, pscale=1.0):
 # Further single-GPU rows (the shapes that were parity-tested but never timed); a few steps each
 EXTRA_ROWS = [
     # tag, overrides
+    # BASELINE.json configs[0] (the reference's own CPU-runnable case): the same shape on the GPU, with the oracle's CPU row
+    ("cfg1_L2_D128_H4_DI256_T256_b64", dict(layers=2, d_model=128, heads=4, d_inner=256, tgt_len=256, mem_len=0,
+                                           batch_per_gpu=64, cpu_row=True)),
     ("L6_D512_T1024_mem1024", dict(mem_len=1024)),
     ("reference_default_L6_D500_dh50_DI1000_T128_M1024_b256_chunk4",
      dict(d_model=500, heads=10, d_inner=1000, tgt_len=128, mem_len=1024, batch_per_gpu=256, batch_chunk=4)),
@@ -429,6 +439,8 @@ def extra_rows(args, dev):
                      "passes_per_step": passes_of(a),
                      "step_mfma_frac": round(f / (elapsed / steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
                      "roofline": attention_roofline(a, prof, tps, elapsed, pscale)}
+        if getattr(a, "cpu_row", False) and not args.no_cpu_baseline:
+            rows[tag]["cpu_baseline"] = cpu_baseline(a)
         if a.mem_len > 0 and not getattr(a, "fp8_forward", False):
             # reset_mems ~ Bernoulli(T / avg_len), avg_len = 512 (capped at 1), so that the reset
             # path (memory tiles skipped per column, zero-filled distances in the backward) is inside a timed region;
@@ -474,8 +486,8 @@ def main():
                     help="forward Linear products of the layers in MX-fp8 (opt-in; bf16 is the default and the headline)")
     ap.add_argument("--graph", dest="graph", action=argparse.BooleanOptionalAction, default=None,
                     help="replay the optimiser step from hipGraphs (Trainer(graph=True)); --no-graph: eager launches; "
-                         "default: graphs when a micro-batch has <= 16384 tokens (there the eager step is bound by the "
-                         "host's launch rate; at the headline shape the eager step with its side streams is faster)")
+                         "default: graphs when a pass is small (tokens x layers x d_model^2 <= 2e13: there the eager step is bound "
+                         "by the host's launch rate; with large kernels the eager step with its side streams is faster)")
     ap.add_argument("--from-iterator", dest="from_iterator", action="store_true",
                     help="also time the step fed by ComMUDataset.get_iterator from an on-disk .npy corpus (on by default "
                          "with the extra rows)")
@@ -524,7 +536,7 @@ def main():
                    "passes_per_step": passes_of(args), "seq_len": T,
                    "dropout": args.dropout, "parallelism": f"dp{world}", "optimizer": "clip1.0+Adam+invsqrt-LR",
                    "launch": ("hipGraph replay (every 4th timed step eager, for the per-kernel events)"
-                              if (args.graph if args.graph is not None else (B // passes_of(args)) * T <= 16384) else "eager"),
+                              if (args.graph if args.graph is not None else auto_graph(args)) else "eager"),
                    "weights": "random init (train.py:291-342)"},
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),
         "step_mfma_frac": round(step_flops / (elapsed / args.steps) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
