@@ -79,7 +79,13 @@ def test_config_shape_loss_and_grads_vs_oracle(case):
         a, b = p.grad.detach().float().cpu().flatten(), oparams[name].grad.flatten()
         cos[name] = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
     assert len(cos) >= 3 + 11 * L
-    bad = {k: v for k, v in cos.items() if v < 0.99}
+    worst = sorted(cos.items(), key=lambda kv: kv[1])[:3]
+    print(f"{tag}: lowest gradient cosines {[(k, round(v, 5)) for k, v in worst]}")
+    # measured: >= 0.9995 everywhere except the first FFN Linear (bf16 pre-activations flip a few ReLU gates against the
+    # fp32 oracle: 0.995-0.999; checked to 6e-2 with the build's gates injected in test_model_gpu) -- and, twelve layers
+    # deep, what those flips do to every gradient below them (0.9957-0.9965)
+    rest = 0.995 if L >= 12 else 0.997
+    bad = {k: v for k, v in cos.items() if v < (0.993 if "pos_ff.CoreNet.0" in k else rest)}
     assert not bad, (tag, bad)
 
 
