@@ -225,8 +225,9 @@ def passes_of(args):
 def auto_graph(args):
     """hipGraph replay of the step pays when the step is host-bound: few tokens per pass through a small model (8 sequences
     x 1024 tokens per GPU at L6 D512: 4.7 instead of 6.1 ms).  With large kernels it does not (cfg-5: 61.5 / 71.9 ms
-    replayed against 59.8 / 66.2 ms eager), so the default follows a work proxy: tokens per pass x layers x d_model^2."""
-    return (args.batch_per_gpu // passes_of(args)) * args.tgt_len * args.layers * args.d_model ** 2 <= 2e13
+    replayed against 59.8 / 66.2 ms eager), so the default follows a work proxy: tokens per pass x layers x d_model^2
+    (8 x 1024 x 6 x 512^2 = 1.3e10: graph; the headline 1.0e11, the merged default config 4.9e10, cfg-5 2.1e11: eager)."""
+    return (args.batch_per_gpu // passes_of(args)) * args.tgt_len * args.layers * args.d_model ** 2 <= 2e10
 
 
 def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
@@ -260,6 +261,8 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
                for i in range(4)]
     tokens_per_step = sum(b[3] for b in batches) // len(batches)
 
+    step_log = [] if os.environ.get("BENCH_STEP_LOG") else None          # (diagnostics: host time of every step() call)
+
     def run(nsteps, base, sample_events=False):
         for i in range(nsteps):
             if sample_events:          # HIP events around the profiled entry points on every fourth step only
@@ -268,10 +271,21 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
                 #  streams -- and the other three quarters of the timed region are graph replays)
                 trainer.graph_mode = use_graph and i % 4 != 0
             d, t, r, n = batches[(base + i) % len(batches)]
+            if step_log is not None:
+                th = time.perf_counter()
             trainer.step(d, t, r, n)
+            if step_log is not None:
+                step_log.append(round(1e3 * (time.perf_counter() - th), 2))
         trainer.graph_mode = use_graph
 
     run(warmup, 0)
+    if use_graph:
+        # the capture + instantiation of the step's graphs (seconds) must not fall into the timed region: keep warming up
+        # until the trainer replays (it captures once the XL memory is full and the optimiser state exists)
+        extra = 0
+        while trainer._graphs is None and trainer.graph_failed is None and extra < 8:
+            run(1, warmup + extra)
+            extra += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -287,6 +301,11 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if step_log is not None:
+        ms = torch.cuda.memory_stats()
+        print(f"[step log] {args.layers}x{args.d_model} T{args.tgt_len} M{args.mem_len} reset {reset_prob}: elapsed {elapsed:.3f} s; "
+              f"host ms per step() {step_log}; reserved {ms['reserved_bytes.all.current'] >> 20} MiB, segments "
+              f"{ms['segment.all.allocated']}, retries {ms['num_alloc_retries']}", file=sys.stderr, flush=True)
     prof = _lib.profile_stop()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -486,7 +505,7 @@ def main():
                     help="forward Linear products of the layers in MX-fp8 (opt-in; bf16 is the default and the headline)")
     ap.add_argument("--graph", dest="graph", action=argparse.BooleanOptionalAction, default=None,
                     help="replay the optimiser step from hipGraphs (Trainer(graph=True)); --no-graph: eager launches; "
-                         "default: graphs when a pass is small (tokens x layers x d_model^2 <= 2e13: there the eager step is bound "
+                         "default: graphs when a pass is small (tokens x layers x d_model^2 <= 2e10: there the eager step is bound "
                          "by the host's launch rate; with large kernels the eager step with its side streams is faster)")
     ap.add_argument("--from-iterator", dest="from_iterator", action="store_true",
                     help="also time the step fed by ComMUDataset.get_iterator from an on-disk .npy corpus (on by default "
