@@ -56,8 +56,8 @@ class DecodeState:
         self.kc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)      # head-major: contiguous per (b, h)
         self.vc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)
         self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
-        pd = ops.posemb(model.pos_emb.inv_freq, Lmax, model.d_model, ld=D)
-        self.rd = [ops.gemm_nt(pd, model._weights(i)["r"]) for i in range(L)]
+        self._pd = ops.posemb(model.pos_emb.inv_freq, Lmax, model.d_model, ld=D)
+        self.rd = [ops.gemm_nt(self._pd, model._weights(i)["r"]) for i in range(L)]
         self.logits = torch.zeros(B, VPAD, device=dev, dtype=F32)          # persistent: re-draws read them again (Q5)
         self.logits_new = torch.zeros(B, VPAD, device=dev, dtype=F32)      # this step's logits before the row select
         self.qkv = torch.zeros(B, 3 * HD, device=dev, dtype=BF16)
@@ -142,23 +142,28 @@ class DecodeState:
 
 
     def repack(self):
-        """(Re)build the packed weight copies the layer-tail launches read (commu_decode_tail_pack): call again whenever
-        the model's weights changed."""
+        """Refresh what the decode step derives from the weights -- the distance tables and the packed weight copies the
+        layer-tail launches read (commu_decode_tail_pack): call again whenever the model's weights changed.  Everything is
+        rewritten IN PLACE: a captured graph keeps pointing at the same buffers."""
+        m = self.model
+        for i in range(m.n_layer):          # the distance tables r_net(pos_emb) depend on the weights too
+            ops.gemm_nt(self._pd, m._weights(i)["r"], out=self.rd[i])
         if not self.tail_ok:
             return
-        m = self.model
 
-        def pack(wt):
+        def pack(wt, out):
             n, k = wt.shape
-            out = torch.empty(call("commu_decode_tail_pack_bytes", n, k) // 2, device=wt.device, dtype=BF16)
+            if out is None:
+                out = torch.empty(call("commu_decode_tail_pack_bytes", n, k) // 2, device=wt.device, dtype=BF16)
             call("commu_decode_tail_pack", _p(wt), wt.stride(0), n, k, _p(out), _s())
             return out
+        old = self.t_packs
         packs = []
         for i in range(m.n_layer):
             w = m._weights(i)
-            packs.append({k: pack(w[k]) for k in ("qkv", "o", "w1", "w2")})
+            packs.append({k: pack(w[k], None if old is None else old[i][k]) for k in ("qkv", "o", "w1", "w2")})
         self.t_packs = packs
-        self.t_pack_e = pack(m._emb_bf16())
+        self.t_pack_e = pack(m._emb_bf16(), None if old is None else self.t_pack_e)
 
     def _step_tail(self, tokens, active, keep, want_logits):
         """step() with one launch per layer after the attention (csrc/decode_tail.hip): embedding, layer 0's QKV Linear,

@@ -482,3 +482,44 @@ def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded, shape):
     print(f"layer tail vs per-Linear chain, {shape}, B={B}, loaded={loaded}: worst logit difference {worst:.2e} of range, "
           f"K cache {kerr:.2e}, V cache {verr:.2e}")
     assert kerr < 2e-2 and verr < 2e-2
+
+
+def test_decoder_reused_after_a_weight_update():
+    """A ForcedDecoder (and its captured graph) outlives weight updates: load() refreshes, IN PLACE, everything the decode
+    step derives from the weights -- the packed copies the layer-tail launches read and the r_net distance tables -- so the
+    replayed graph decodes with the new weights.  Sampled sequences (same variates) of the reused decoder == a fresh
+    decoder's (eager), and != the sequences before the update."""
+    from commu_amd.generate import ForcedDecoder
+    from test_configs_gpu import build
+    model, cfg, s, params = build(6, 8, 512, 1024, 1, 4146, seed=31)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    with torch.no_grad():
+        bias = model.crit.out_layers[0].bias
+        bias.zero_()
+        bias[1:3] = -1e9                      # no EOS / BAR, no chord tokens: every iteration is a model step and a draw
+        bias[195:304] = -1e9
+    meta = [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
+    data = types.SimpleNamespace(num_measures=4.0, chord_token_components={"chord_token": [], "chord_position": []})
+
+    uni = np.random.RandomState(4).random_sample((4, 64)).astype(np.float32)
+
+    def run(dec, graph):
+        dec.load([meta] * 4, [data] * 4, uni)
+        with torch.no_grad():
+            dec.run(use_graph=graph)
+        return dec.sequences()[0]
+    dec = ForcedDecoder(model, 4, generation_length=40, memory_length=4146, temperature=0.95, top_k=32)
+    assert dec.state.tail_ok
+    before = run(dec, True)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 2 and "emb" not in n:
+                p.add_((0.05 * torch.randn(p.shape, generator=g)).to(p.device))
+    model._refresh_shadows()
+    after = run(dec, True)                                   # same decoder, same captured graph
+    fresh = run(ForcedDecoder(model, 4, generation_length=40, memory_length=4146, temperature=0.95, top_k=32), False)
+    assert after == fresh
+    assert after != before
