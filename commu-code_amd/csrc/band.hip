@@ -284,8 +284,7 @@ extern "C" int commu_relattn_bwd_band(const void* dsk, int ld_dsk, const void* r
     a.slabs = slabs;
     a.TB = (int)TB; a.K = K; a.H = H; a.tri_B = band ? B : 0; a.tri_M = M;
     a.nsteps = (int)(TB / 64); a.P = P; a.sps = (a.nsteps + 2 * P - 1) / (2 * P);
-    a.abl = 0;
-    if (const char* e = getenv("COMMU_BAND_ABL")) a.abl = atoi(e);
+    a.abl = 0;          // (profiling ablations are compiled in but never enabled from the product path)
     COMMU_LAUNCH(band_bwd_kernel, dim3(H * P), dim3(512), 0, stream, a);
     COMMU_LAUNCH_CHECK();
     return 0;

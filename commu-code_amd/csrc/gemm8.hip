@@ -786,8 +786,6 @@ int launch_gemm8_nt(const G8Args& a_in, hipStream_t stream) {
         const int gsz = atoi(e);
         if (gsz > 0 && gsz < grid) grid = gsz;
     }
-    int abl = 0;
-    if (const char* e = getenv("COMMU_GEMM8_ABL")) abl = atoi(e);
     G8Args a = a_in;
     a.skew_cycles = 0;
     if (const char* e = getenv("COMMU_GEMM8_SKEW")) a.skew_cycles = atoi(e);
@@ -801,15 +799,10 @@ int launch_gemm8_nt(const G8Args& a_in, hipStream_t stream) {
         COMMU_LAUNCH((gemm_nt8_kernel<false, 0, 2>), dim3(grid), dim3(512), 0, stream, a);
     } else if (a.flags & COMMU_EPI_RELUBITS) {
         COMMU_LAUNCH((gemm_nt8_kernel<false, 0, 3>), dim3(grid), dim3(512), 0, stream, a);
-    } else if (pipe && abl == 0 && !(a.flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK))) {
+    } else if (pipe && !(a.flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK))) {
         COMMU_LAUNCH((gemm_nt8_kernel<false, 0, 1>), dim3(grid), dim3(512), 0, stream, a);
     } else {
-        switch (abl) {
-            case 1: G8_LAUNCH(false, 1); break;
-            case 2: G8_LAUNCH(false, 2); break;
-            case 3: G8_LAUNCH(false, 3); break;
-            default: G8_LAUNCH(false, 0); break;
-        }
+        G8_LAUNCH(false, 0);          // (ABL != 0 -- fake MFMA / no staging / no epilogue -- are profiling builds: never launched)
     }
 #undef G8_LAUNCH
     COMMU_LAUNCH_CHECK();

@@ -1,4 +1,5 @@
-"""gemm8 timing at the step's NT shapes + long-K shapes; env sweeps: COMMU_GEMM8_ABL (ablations), COMMU_GEMM8_SKEW."""
+"""gemm8 timing at the step's NT shapes + long-K shapes; env sweep COMMU_GEMM8_SKEW (the COMMU_GEMM8_ABL ablation switch this probe
+also swept was removed from the library: the ablated kernels compute wrong results and are not reachable from the product path)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "commu-code_amd"))

@@ -34,7 +34,7 @@ y = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
 y2 = torch.empty(M, 1024, device=dev, dtype=torch.bfloat16)
 b = torch.randn(1024, device=dev)
 r = torch.randn(M, 1024, device=dev).bfloat16()
-if os.environ.get("SWEEP_ABL"):
+if os.environ.get("SWEEP_ABL"):          # (needs a library built with the COMMU_GEMM8_ABL switch, removed from the product)
     for abl in ("0", "1", "2", "3"):
         os.environ["COMMU_GEMM8_ABL"] = abl
         t = timeit(lambda: ops.gemm_nt(x, w, out=y))
