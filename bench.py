@@ -151,6 +151,44 @@ def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
                          "bytes_per_step": int(bytes_step)}}
 
 
+def decode_to_completion(dev, args, B=64):
+    """the same 64-way generation run TO COMPLETION instead of a fixed number of iterations --
+    ForcedDecoder.run() as generate.py uses it (graph replays, done flags polled every 16 iterations) until every sequence
+    has drawn EOS (or a bar with no chords left, which forces EOS) or reached 4096 iterations.  Random-init weights: the
+    lengths are geometric (a few hundred tokens), so the batch thins out as it goes -- tokens/s counts the tokens actually
+    generated over the wall time of the whole call, including the iterations in which few sequences are still alive."""
+    import types
+    from commu_amd.generate import ForcedDecoder
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab
+    from commu_amd.train import build_model
+    cfg = get_cfg(num_layers=args.layers, num_heads=args.heads, units=args.d_model, inner_size=args.d_inner,
+                  tgt_length=1, mem_length=4146, dropout=0.0, attention_dropout=0.0, same_length=True)
+    model = build_model(cfg, BaseVocab(), dev, seed=1).eval()
+    with torch.no_grad():
+        bias = model.crit.out_layers[0].bias
+        bias.zero_()
+        bias[195:304] = -1e9                      # no chord tokens (they would be rejected and redrawn: no progression given)
+        dec = ForcedDecoder(model, B, generation_length=4096, memory_length=4146, temperature=0.95, top_k=32)
+        data = types.SimpleNamespace(num_measures=4.0, chord_token_components={"chord_token": [], "chord_position": []})
+        meta = [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
+        uni = torch.rand(B, dec.ld_u, generator=torch.Generator().manual_seed(5)).numpy()
+        dec.load([meta] * B, [data] * B, uni)
+        dec.run(use_graph=True)                   # builds the graph; a first, untimed generation
+        dec.load([meta] * B, [data] * B, uni)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec.run(use_graph=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        seqs, _ = dec.sequences()
+    lens = [len(s_) - 12 for s_ in seqs if s_ is not None]          # tokens generated after the 12-token context
+    iters = int(dec.fsm[:, 7].max().item())
+    return {"tokens_per_s": round(sum(lens) / dt, 1), "wall_ms": round(1e3 * dt, 2), "sequences": B, "finished": len(lens),
+            "generated_tokens": int(sum(lens)), "longest_sequence_iterations": iters,
+            "mean_tokens_per_sequence": round(sum(lens) / max(1, len(lens)), 1), "hipgraph": True}
+
+
 def decode_cpu_baseline(args, steps=256):
     """The oracle's generation step (oracle/xl_ref.forward_generate: the reference's forward_generate restated, full
     QKV recomputation over the memory every step) + the oracle's sampling step, batch 1, sequential like the reference
@@ -570,7 +608,8 @@ def main():
         out["decode"] = {"metric": "autoregressive decode tokens/sec (64 sequences in parallel, device-resident forcing "
                                    "+ K/V-cache step + top-k 32 / T 0.95 sampling in one hipGraph per iteration)",
                          "short_memory": decode_bench(dev, args, 11), "long_memory": decode_bench(dev, args, 1000),
-                         "long_memory_no_graph": decode_bench(dev, args, 1000, steps=128, graph=False)}
+                         "long_memory_no_graph": decode_bench(dev, args, 1000, steps=128, graph=False),
+                         "to_completion": decode_to_completion(dev, args)}
         if not args.no_cpu_baseline:
             out["decode"]["cpu_baseline"] = decode_cpu_baseline(args)
     if world == 1 and not args.no_cpu_baseline:
