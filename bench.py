@@ -184,9 +184,42 @@ def decode_to_completion(dev, args, B=64):
         seqs, _ = dec.sequences()
     lens = [len(s_) - 12 for s_ in seqs if s_ is not None]          # tokens generated after the 12-token context
     iters = int(dec.fsm[:, 7].max().item())
-    return {"tokens_per_s": round(sum(lens) / dt, 1), "wall_ms": round(1e3 * dt, 2), "sequences": B, "finished": len(lens),
-            "generated_tokens": int(sum(lens)), "longest_sequence_iterations": iters,
-            "mean_tokens_per_sequence": round(sum(lens) / max(1, len(lens)), 1), "hipgraph": True}
+    out = {"tokens_per_s": round(sum(lens) / dt, 1), "wall_ms": round(1e3 * dt, 2), "sequences": B, "finished": len(lens),
+           "generated_tokens": int(sum(lens)), "longest_sequence_iterations": iters,
+           "mean_tokens_per_sequence": round(sum(lens) / max(1, len(lens)), 1), "hipgraph": True}
+    # bulk request: 256 sequences through the same 64 slots.  Rounds of 64 (each round thins out towards its end) against
+    # BatchedGenerator.generate_stream (a finished slot is re-armed with the next attempt at once: what generate.py does)
+    from commu_amd.generate import BatchedGenerator
+    gen = BatchedGenerator(model, dev, 4096, 4146)
+    with torch.no_grad():
+        ntok = [0]
+
+        def accept(seq, rep):
+            ntok[0] += 0 if seq is None else len(seq) - 12
+            return True
+        gen.generate_stream(meta, data, 0.95, 32, need=B, accept=accept, slots=B, seed=3)          # (graph build, untimed)
+        ntok[0] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got, started = gen.generate_stream(meta, data, 0.95, 32, need=4 * B, accept=accept, slots=B, seed=3)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        stream_tokens = sum(len(s_) - 12 for s_ in got)          # tokens of the 256 returned sequences only
+        t0 = time.perf_counter()
+        rtok = 0
+        for r in range(4):
+            gen.uniform_sources = [(lambda a=a: iter(BatchedGenerator.attempt_uniforms(3, a, 4097)).__next__)() for a in
+                                   range(r * B, (r + 1) * B)]
+            seqs_r, _ = gen.generate([meta] * B, [data] * B, 0.95, 32)
+            rtok += sum(len(s_) - 12 for s_ in seqs_r if s_ is not None)
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t0
+    out["bulk_256_sequences"] = {
+        "continuous_slots": {"tokens_per_s": round(stream_tokens / dts, 1), "wall_ms": round(1e3 * dts, 1),
+                             "accepted": len(got), "attempts_started": started, "tokens_of_accepted": int(stream_tokens),
+                             "tokens_of_all_attempts": int(ntok[0])},
+        "rounds_of_64": {"tokens_per_s": round(rtok / dtr, 1), "wall_ms": round(1e3 * dtr, 1), "tokens": int(rtok)}}
+    return out
 
 
 def decode_cpu_baseline(args, steps=256):

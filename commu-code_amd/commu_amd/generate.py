@@ -364,6 +364,41 @@ class ForcedDecoder:
             u[:, :n] = uniforms[:, :n]
             self.utable.copy_(torch.from_numpy(u))
 
+    # ---- slots: a finished sequence's slot can be re-armed for another attempt of the SAME request (same conditioning
+    # tokens and chords) without touching the other slots: the context rows of its K/V cache are what they were, so only
+    # the state record, the lengths, the rejected-token map and the variates are reset.  The re-armed slot sits out the
+    # iteration in flight (its decision was taken from the finished record) and starts with the next one.
+    def rearm(self, b: int, uniforms_row: Optional[np.ndarray] = None):
+        rep0 = self.reports[b]
+        rep = ForcingReport(rep0.n_chords, rep0.num_measures)
+        self.reports[b] = rep
+        rec = [1 + self.n_cond, -1, 0, 1, int(rep.num_measures % 4 == 0), 0, 0, 0, 0, rep.n_chords, 0,
+               int(rep.length_fit), 0, 0]
+        self.fsm[b].copy_(torch.tensor(rec, dtype=torch.int32))
+        self.wrong[b].zero_()
+        self.state.klen[b] = self.n_cond
+        if uniforms_row is not None:
+            u = np.full(self.ld_u, 0.5, dtype=np.float32)
+            n = min(len(uniforms_row), self.ld_u)
+            u[:n] = uniforms_row[:n]
+            self.utable[b].copy_(torch.from_numpy(u))
+        if self.trace is not None:
+            self.trace[b].zero_()
+
+    def harvest(self, b: int, fsm_row):
+        """Token list of slot b (None where nothing could be drawn, Q12) from its downloaded state record."""
+        self.reports[b].consumed = int(fsm_row[10])
+        if fsm_row[6]:
+            return None
+        return self.seq[b, :int(fsm_row[0])].cpu().tolist()
+
+    def run_iterations(self, n: int, use_graph: bool = True):
+        for _ in range(n):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self.body_pre()
+
     def run(self, use_graph: bool = True):
         if use_graph and self.graph is None:
             self.build_graph()
@@ -436,3 +471,63 @@ class BatchedGenerator:
         if self.trace is not None:
             self.trace[:] = traces
         return seqs, dec.reports
+
+    @staticmethod
+    def attempt_uniforms(seed: int, attempt: int, n: int) -> np.ndarray:
+        """The variates of attempt number `attempt` of a request (its own stream: an attempt's sequence does not depend on
+        which slot or how many other attempts ran beside it)."""
+        return np.random.RandomState((seed + 7919 * attempt) % (2 ** 32)).random_sample(n).astype(np.float32)
+
+    @torch.no_grad()
+    def generate_stream(self, encoded_meta: Sequence[int], input_data, temperature: float, top_k: int, need: int,
+                        accept, top_p: float = 1.0, slots: int = 64, seed: int = 0, max_attempts: Optional[int] = None):
+        """Attempts of ONE request (the reference's `while idx != num_generate` loop, midi_inferrer.py:338-354, which tries
+        one sequence after the other) decoded in up to `slots` parallel slots, CONTINUOUSLY: a slot whose sequence has
+        ended is handed to `accept(sequence, report) -> bool` and re-armed with the next attempt while the other slots keep
+        decoding -- the batch does not thin out towards the end of a round.  Returns (the first `need` accepted attempts IN
+        ATTEMPT ORDER -- exactly what the reference's sequential loop would return for the same per-attempt variates,
+        whatever the number of slots --, attempts started); fewer when `max_attempts` attempts did not yield `need`.
+        Attempt a draws from attempt_uniforms(seed, a, .) whichever slot decodes it."""
+        B = max(1, min(int(slots), int(need)))
+        max_chords = len(input_data.chord_token_components["chord_token"])
+        dec = self.decoder(B, temperature, top_k, max_chords, top_p)
+        started = B
+        uni = np.stack([self.attempt_uniforms(seed, a, dec.ld_u) for a in range(B)]) if temperature != 0 else None
+        dec.load([list(encoded_meta)] * B, [input_data] * B, uni)
+        if self.use_graph and dec.graph is None:
+            dec.build_graph()
+        dec.pre()
+        slot_attempt = list(range(B))          # attempt number decoded in each slot; -1: slot retired
+        results = {}                           # attempt -> its sequence if accepted, False if rejected
+        n_ok, out = 0, None
+        while out is None and any(a >= 0 for a in slot_attempt):
+            dec.run_iterations(dec.POLL, self.use_graph)
+            fsm = dec.fsm.cpu().numpy()        # the one synchronisation per POLL iterations
+            for b in range(B):
+                a = slot_attempt[b]
+                if a < 0 or not fsm[b, 5]:
+                    continue
+                seq = dec.harvest(b, fsm[b])
+                ok = bool(accept(seq, dec.reports[b]))
+                results[a] = seq if ok else False
+                n_ok += ok
+                # no further attempts once enough were accepted: only the lower-numbered ones still in flight can matter
+                if n_ok >= need or (max_attempts is not None and started >= max_attempts):
+                    slot_attempt[b] = -1
+                    continue
+                dec.rearm(b, self.attempt_uniforms(seed, started, dec.ld_u) if temperature != 0 else None)
+                slot_attempt[b] = started
+                started += 1
+            # the answer: the first `need` accepted attempts IN ATTEMPT ORDER, known once every attempt before the last of
+            # them has ended (taking them in order of completion instead would favour short sequences)
+            got, a = [], 0
+            while a in results and len(got) < need:
+                if results[a] is not False:
+                    got.append(results[a])
+                a += 1
+            if len(got) >= need:
+                out = got
+        if out is None:                        # max_attempts exhausted: whatever was accepted, in attempt order
+            out = [results[a] for a in sorted(results) if results[a] is not False][:need]
+        dec.state.check()
+        return out, started

@@ -39,27 +39,22 @@ class TokenGenerationPipeline:
         data = self.preprocess_task.input_data
         checker = InferenceTask(self.device)                            # only its validator is used here
         gen = BatchedGenerator(self.model, self.device, self.generation_length, self.memory_length)
-        out: List[List[int]] = []
-        rounds = 0
-        while len(out) < data.num_generate and (max_rounds is None or rounds < max_rounds):
-            want = data.num_generate - len(out)
-            gen.uniform_sources = [np.random.RandomState(uniform_seed + 7919 * rounds + b).random_sample
-                                   for b in range(want)]
-            seqs, reports = gen.generate([encoded_meta] * want, [data] * want, data.temperature, data.top_k,
-                                         top_p=getattr(data, "top_p", 1.0))
-            for seq, teacher in zip(seqs, reports):
-                self.attempts += 1
-                if seq is None:
-                    self.rejected.append(("sampling", None))
-                    continue
-                try:
-                    teacher.validate_teacher_forced_sequence(seq)
-                except Exception:
-                    self.rejected.append(("forcing", seq))
-                    continue
-                if checker.validate_generated_sequence(seq):
-                    out.append(seq)
-                else:
-                    self.rejected.append(("no_note", seq))
-            rounds += 1
+
+        def accept(seq, teacher) -> bool:
+            self.attempts += 1
+            if seq is None:
+                self.rejected.append(("sampling", None))
+                return False
+            try:
+                teacher.validate_teacher_forced_sequence(seq)
+            except Exception:
+                self.rejected.append(("forcing", seq))
+                return False
+            if checker.validate_generated_sequence(seq):
+                return True
+            self.rejected.append(("no_note", seq))
+            return False
+        out, _ = gen.generate_stream(encoded_meta, data, data.temperature, data.top_k, data.num_generate, accept,
+                                     top_p=getattr(data, "top_p", 1.0), seed=uniform_seed,
+                                     max_attempts=None if max_rounds is None else max_rounds * data.num_generate)
         return out

@@ -95,23 +95,19 @@ class InferenceTask:
         glen = self.inference_cfg.GENERATION.generation_length
         mlen = getattr(self.inference_cfg.MODEL, "memory_length", 4146) if hasattr(self.inference_cfg, "MODEL") else 4146
         gen = BatchedGenerator(self.model, self.device, glen, mlen)
-        out: List[List[int]] = []
-        rounds = 0
-        while len(out) < data.num_generate and (max_rounds is None or rounds < max_rounds):
-            want = data.num_generate - len(out)
-            gen.uniform_sources = [np.random.RandomState(self.uniform_seed + 7919 * rounds + b).random_sample
-                                   for b in range(want)]
-            seqs, reports = gen.generate([list(encoded_meta)] * want, [data] * want, data.temperature, data.top_k,
-                                         top_p=getattr(data, "top_p", 1.0))
-            for seq, rep in zip(seqs, reports):
-                self.attempts += 1
-                if seq is None:
-                    continue
-                try:
-                    rep.validate_teacher_forced_sequence(seq)
-                except Exception:
-                    continue
-                if self.validate_generated_sequence(seq):
-                    out.append(seq)
-            rounds += 1
+
+        def accept(seq, rep) -> bool:
+            self.attempts += 1
+            if seq is None:
+                return False
+            try:
+                rep.validate_teacher_forced_sequence(seq)
+            except Exception:
+                return False
+            return self.validate_generated_sequence(seq)
+        # attempts decoded in up to 64 slots, a finished slot re-armed with the next attempt (the reference tries one
+        # sequence after the other until num_generate passed; `max_rounds` bounds the attempts at max_rounds x num_generate)
+        out, _ = gen.generate_stream(list(encoded_meta), data, data.temperature, data.top_k, data.num_generate, accept,
+                                     top_p=getattr(data, "top_p", 1.0), seed=self.uniform_seed,
+                                     max_attempts=None if max_rounds is None else max_rounds * data.num_generate)
         return out

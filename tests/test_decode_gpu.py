@@ -523,3 +523,82 @@ def test_decoder_reused_after_a_weight_update():
     fresh = run(ForcedDecoder(model, 4, generation_length=40, memory_length=4146, temperature=0.95, top_k=32), False)
     assert after == fresh
     assert after != before
+
+
+def test_generate_stream_rearms_finished_slots():
+    """BatchedGenerator.generate_stream: 150 attempts of one request through 64 slots, a finished slot re-armed with the
+    next attempt while the others keep decoding.  Every attempt draws from its own variate stream, so its sequence must
+    be the one the attempt produces when it is decoded in a plain 64-way batch from a fresh start (a re-armed slot reuses
+    the context rows of its K/V cache and resets everything else): attempts 0..63 (first occupants) and 64..127 (second
+    occupants of the same slots) are compared token for token."""
+    from commu_amd.generate import BatchedGenerator, ForcedDecoder
+    from test_configs_gpu import build
+    model, cfg, s, params = build(6, 8, 512, 1024, 1, 4146, seed=37)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    with torch.no_grad():
+        bias = model.crit.out_layers[0].bias
+        bias.zero_()
+        bias[1:3] = -1e9                      # no EOS / BAR, no chord tokens: every attempt runs its 48 iterations
+        bias[195:304] = -1e9
+    meta = [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
+    data = types.SimpleNamespace(num_measures=4.0, chord_token_components={"chord_token": [], "chord_position": []})
+    gen = BatchedGenerator(model, torch.device(DEV), generation_length=48, memory_length=4146)
+    seen = []
+
+    def accept(seq, rep):
+        seen.append(seq)
+        return True
+    out, started = gen.generate_stream(meta, data, 0.95, 32, need=150, accept=accept, slots=64, seed=11)
+    assert len(out) == 150 and 150 <= started <= 214 and len(seen) >= 150
+    assert all(s_ is not None and s_[:12] == [0] + meta and len(s_) == 12 + 48 for s_ in out)
+    for first in (0, 64):
+        dec = ForcedDecoder(model, 64, generation_length=48, memory_length=4146, temperature=0.95, top_k=32)
+        uni = np.stack([BatchedGenerator.attempt_uniforms(11, first + b, dec.ld_u) for b in range(64)])
+        dec.load([meta] * 64, [data] * 64, uni)
+        with torch.no_grad():
+            dec.run(use_graph=False)
+        ref = dec.sequences()[0]
+        assert out[first:first + 64] == ref, first
+    assert len({tuple(s_) for s_ in out}) > 20           # the attempts differ (a random-init tied embedding mostly repeats its input)
+
+
+def test_generate_stream_returns_the_sequential_loops_answer():
+    """With ragged lengths (EOS is likely) and a validator that rejects some attempts, generate_stream returns the first
+    `need` accepted attempts IN ATTEMPT ORDER -- what the reference's one-after-the-other loop (midi_inferrer.py:338-354)
+    would return for the same per-attempt variates -- not the first to finish: compared with all attempts decoded in plain
+    64-way batches and filtered in order.  Slots are re-armed at different times here."""
+    from commu_amd.generate import BatchedGenerator, ForcedDecoder
+    from test_configs_gpu import build
+    model, cfg, s, params = build(6, 8, 512, 1024, 1, 4146, seed=41)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    with torch.no_grad():
+        bias = model.crit.out_layers[0].bias
+        bias.zero_()
+        bias[1] = 3.0                         # EOS is drawn every few dozen tokens: lengths differ
+        bias[2] = -1e9
+        bias[195:304] = -1e9
+    meta = [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
+    data = types.SimpleNamespace(num_measures=4.0, chord_token_components={"chord_token": [], "chord_position": []})
+    GL, NEED = 96, 50
+
+    def accept(seq, rep):
+        return seq is not None and len(seq) % 3 != 0
+    gen = BatchedGenerator(model, torch.device(DEV), generation_length=GL, memory_length=4146)
+    out, started = gen.generate_stream(meta, data, 0.95, 32, need=NEED, accept=accept, slots=64, seed=5)
+    allseq = []
+    for first in range(0, 256, 64):
+        dec = ForcedDecoder(model, 64, generation_length=GL, memory_length=4146, temperature=0.95, top_k=32)
+        uni = np.stack([BatchedGenerator.attempt_uniforms(5, first + b, dec.ld_u) for b in range(64)])
+        dec.load([meta] * 64, [data] * 64, uni)
+        with torch.no_grad():
+            dec.run(use_graph=False)
+        allseq += dec.sequences()[0]
+    lens = sorted(len(s_) for s_ in allseq)
+    assert lens[0] < lens[-1] - 20, "the attempts should have different lengths"
+    want = [s_ for s_ in allseq if accept(s_, None)][:NEED]
+    assert len(want) == NEED and out == want
+    assert NEED <= started <= 256
