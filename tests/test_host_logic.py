@@ -307,3 +307,23 @@ def test_oracle_nucleus_filter_known_answers():
     assert torch.allclose(Dz.apply_top_p(p, 0.9), torch.tensor([0.0, 0.4, 0.1, 0.25, 0.2]) / 0.95)
     t = torch.tensor([0.2, 0.2, 0.2, 0.2, 0.2])                     # ties: lowest id first
     assert torch.allclose(Dz.apply_top_p(t, 0.5), torch.tensor([1.0, 1.0, 1.0, 0.0, 0.0]) / 3)
+
+
+def test_bench_launch_mode_defaults():
+    """bench.py's defaults: the step is replayed from hipGraphs only where it is host-bound (8 sequences per GPU, the tiny
+    cfg-1 model); the headline, the merged default config and cfg-5 run eager (a replayed step is slower there, and a graph
+    captured inside a timed region costs seconds).  The micro-batches of the released default config fold into one pass."""
+    import argparse
+    import bench
+    base = dict(layers=6, d_model=512, heads=8, d_inner=1024, tgt_len=1024, mem_len=0, batch_per_gpu=64, batch_chunk=1,
+                merge_chunks=None)
+    ns = lambda **kw: argparse.Namespace(**{**base, **kw})
+    assert not bench.auto_graph(ns())                                                        # the headline
+    assert bench.auto_graph(ns(batch_per_gpu=8))                                             # strong scaling over 8 GPUs
+    assert bench.auto_graph(ns(layers=2, d_model=128, heads=4, d_inner=256, tgt_len=256))    # cfg-1
+    assert not bench.auto_graph(ns(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048,
+                                   batch_per_gpu=8))                                         # cfg-5
+    default = ns(d_model=500, heads=10, d_inner=1000, tgt_len=128, mem_len=1024, batch_per_gpu=256, batch_chunk=4)
+    assert bench.passes_of(default) == 1 and not bench.auto_graph(default)
+    assert bench.passes_of(ns(batch_chunk=4, merge_chunks=False)) == 4
+    assert bench.passes_of(ns(tgt_len=2048, batch_per_gpu=64, batch_chunk=2)) == 2          # 131 072 tokens: the loop
