@@ -31,7 +31,6 @@ class TokenGenerationPipeline:
         """input_args: the reference's input dictionary (generate.py:17-44).  Runs rounds of parallel decoding until
         `num_generate` sequences passed both validators (the reference retries one sequence at a time forever;
         `max_rounds` bounds it)."""
-        import numpy as np
         self.model.eval()
         self.model.same_length = True                                   # model_initializer.py:49-50
         self.model.reset_length(1, self.memory_length)

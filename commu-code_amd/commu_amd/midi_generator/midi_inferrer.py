@@ -89,7 +89,6 @@ class InferenceTask:
         return count_notes(seq) > 0
 
     def execute(self, encoded_meta, max_rounds: Optional[int] = None) -> List[List[int]]:    # :338-354
-        import numpy as np
         from ..generate import BatchedGenerator
         data = self.input_data
         glen = self.inference_cfg.GENERATION.generation_length

@@ -11,8 +11,6 @@ Differences that do not change the arithmetic:
 """
 from __future__ import annotations
 
-import math
-import time
 from typing import List, Optional
 
 import torch
