@@ -122,16 +122,16 @@ def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
 
         dec.pre()
 
-        def run(n):
-            done = 0
+        def run(n):          # (ForcedDecoder.run's loop with a fixed iteration count: done flags polled one window late, no stall)
+            done, live, pending = 0, True, False
             while done < n:
-                for _ in range(dec.POLL):
-                    if graph:
-                        dec.graph.replay()
-                    else:
-                        dec.body_pre()
+                dec.run_iterations(dec.POLL, graph)
                 done += dec.POLL
-                live = not bool(dec.fsm[:, 5].all().item())
+                if pending:
+                    live = live and not bool(dec.poll_result()[:, 5].all())
+                dec.poll_submit()
+                pending = True
+            live = live and not bool(dec.poll_result()[:, 5].all())
             return done, live
         run(16)
         torch.cuda.synchronize()

@@ -392,6 +392,22 @@ class ForcedDecoder:
             return None
         return self.seq[b, :int(fsm_row[0])].cpu().tolist()
 
+    # ---- done flags without stalling the GPU: the flags of window k are copied to pinned memory behind window k and
+    # looked at after window k + 1 has been queued, so the device never waits for the host between windows (a
+    # synchronous read costs the wake-up + first launch, ~60 us per 16 iterations); the price is that up to POLL
+    # iterations are queued beyond the one that finished the last sequence (they do nothing: every slot is inactive)
+    def poll_submit(self):
+        if getattr(self, "_done_pin", None) is None:
+            self._done_pin = torch.zeros(self.B, self.NF, dtype=torch.int32).pin_memory()
+            self._done_ev = torch.cuda.Event()
+        self._done_pin.copy_(self.fsm, non_blocking=True)
+        self._done_ev.record()
+
+    def poll_result(self):
+        """The state records as of the last poll_submit (numpy [B, NF]; waits for that copy only)."""
+        self._done_ev.synchronize()
+        return self._done_pin.numpy().copy()
+
     def run_iterations(self, n: int, use_graph: bool = True):
         for _ in range(n):
             if use_graph:
@@ -403,16 +419,15 @@ class ForcedDecoder:
         if use_graph and self.graph is None:
             self.build_graph()
         self.pre()                                          # decision of the first iteration
-        it = 0
+        it, pending = 0, False
         while it < self.generation_length + 1:
-            for _ in range(self.POLL):
-                if use_graph:
-                    self.graph.replay()
-                else:
-                    self.body_pre()
+            self.run_iterations(self.POLL, use_graph)
             it += self.POLL
-            if bool(self.fsm[:, 5].all().item()):          # every record's `done` flag (the one sync per POLL steps)
+            if pending and bool(self.poll_result()[:, 5].all()):          # the records one window back: no stall
                 break
+            self.poll_submit()
+            pending = True
+        torch.cuda.current_stream().synchronize()
         self.state.check()
 
     def sequences(self):
@@ -500,9 +515,11 @@ class BatchedGenerator:
         slot_attempt = list(range(B))          # attempt number decoded in each slot; -1: slot retired
         results = {}                           # attempt -> its sequence if accepted, False if rejected
         n_ok, out = 0, None
+        dec.run_iterations(dec.POLL, self.use_graph)
         while out is None and any(a >= 0 for a in slot_attempt):
-            dec.run_iterations(dec.POLL, self.use_graph)
-            fsm = dec.fsm.cpu().numpy()        # the one synchronisation per POLL iterations
+            dec.poll_submit()                  # the records after the window just queued ...
+            dec.run_iterations(dec.POLL, self.use_graph)          # ... are read while the next window runs
+            fsm = dec.poll_result()
             for b in range(B):
                 a = slot_attempt[b]
                 if a < 0 or not fsm[b, 5]:
