@@ -48,14 +48,14 @@ __device__ __forceinline__ int wscan_i(int v, int lane) {
 constexpr int PER_LANE = 12;      // 64 * 12 = 768 >= 729: lane l owns ids [12 l, 12 l + 12)
 
 // one wave per sequence b (lane = threadIdx.x of a 64-thread workgroup)
-__device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restrict__ logits, int ld, int V,
+__device__ __forceinline__ int sample_topk_body(int b, int lane, float* __restrict__ logits, int ld, int V,
                                                  const unsigned char* __restrict__ wrong, int ldw,
                                                  const float* __restrict__ uni,
                                                  const unsigned char* __restrict__ active, float temperature,
                                                  int top_k, int* __restrict__ token, float* __restrict__ probs_out,
                                                  int ldp, float top_p = 1.f) {
-    if (active != nullptr && !active[b]) return;
-    float* lg = logits + (size_t)b * ld;
+    const unsigned char act = active != nullptr ? active[b] : (unsigned char)1;          // (tested after the loads below are
+    float* lg = logits + (size_t)b * ld;                                                  //  issued: one round trip, not two)
     float p[PER_LANE];
     const int base = lane * PER_LANE;
     // every load of the step up front and unconditional (clamped index): one memory round trip, not one per element
@@ -72,6 +72,7 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
             if (base + e < V && wb[e] != 0) wmask |= 1u << e;
     }
     const float u = uni != nullptr ? uni[b] : 0.5f;
+    if (!act) return -2;
     // ---- calc_probs
     if (temperature == 0.f) {
         float best = -INFINITY;
@@ -185,7 +186,7 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
         if (probs_out != nullptr)
             for (int e = 0; e < PER_LANE; ++e)
                 if (base + e < V) probs_out[(size_t)b * ldp + base + e] = NAN;
-        return;
+        return -1;
     }
     const float inv = 1.f / tot;
     float ls = 0.f;
@@ -253,7 +254,9 @@ __device__ __forceinline__ void sample_topk_body(int b, int lane, float* __restr
         if (p[e] > 0.f) last = base + e;
     cand = wmin_i(cand);
     last = wmax_i(last);
-    if (lane == 0) token[b] = (cand == (1 << 30)) ? last : cand;
+    const int drawn = (cand == (1 << 30)) ? last : cand;
+    if (lane == 0) token[b] = drawn;
+    return drawn;
 }
 
 
@@ -280,13 +283,23 @@ enum {
     F_COUNT
 };
 
-__device__ __forceinline__ void forcing_pre_body(int b, int lane, int* st, int* seq, int ld_seq,
+// The state record of a sequence as registers of lane 0: loaded with one batch of loads, stored back once (the record's
+// fields are read and written many times by the transitions; through memory every access after a store is a round trip).
+__device__ __forceinline__ void record_load(int (&r)[F_COUNT], const int* st, int b) {
+#pragma unroll
+    for (int f = 0; f < F_COUNT; ++f) r[f] = st[(size_t)b * F_COUNT + f];
+}
+__device__ __forceinline__ void record_store(const int (&r)[F_COUNT], int* st, int b) {
+#pragma unroll
+    for (int f = 0; f < F_COUNT; ++f) st[(size_t)b * F_COUNT + f] = r[f];
+}
+
+__device__ __forceinline__ void forcing_pre_body(int b, int lane, int (&s)[F_COUNT], int* seq, int ld_seq,
                                                  const int* __restrict__ chord_tok, const int* __restrict__ chord_pos,
                                                  int ld_chord, unsigned char* wrong, const float* __restrict__ utable,
                                                  int ld_u, int max_iters, long long* tok, unsigned char* active,
                                                  unsigned char* keep, unsigned char* draw, float* uni, int* trace,
                                                  int ld_trace) {
-    int* s = st + (size_t)b * F_COUNT;
     int* sq = seq + (size_t)b * ld_seq;
     int clear = 0;
     if (lane == 0) {
@@ -357,17 +370,17 @@ __device__ __forceinline__ void forcing_pre_body(int b, int lane, int* st, int* 
         for (int i = lane; i < VOCAB; i += 64) wrong[(size_t)b * VOCAB + i] = 0;
 }
 
-__device__ __forceinline__ void forcing_post_body(int b, int lane, int* st, int* seq, int ld_seq,
+// token_val: the token drawn this iteration when the caller has it in a register (>= -1), else (-3) it is read from token[b]
+__device__ __forceinline__ void forcing_post_body(int b, int lane, int (&s)[F_COUNT], int* seq, int ld_seq,
                                                   const int* __restrict__ chord_pos, int ld_chord, unsigned char* wrong,
                                                   const unsigned char* draw, const int* token, int* live, int* klen,
-                                                  const unsigned char* keep, int lmax) {
-    int* s = st + (size_t)b * F_COUNT;
+                                                  const unsigned char* keep, int lmax, int token_val = -3) {
     int clear = 0;
     if (lane == 0) {
         // memory length of the step that just ran: it grows unless the step's memory is discarded (quirk Q3)
         if (klen != nullptr && keep[b] && klen[b] < lmax - 1) klen[b] += 1;
         if (draw[b]) {
-            const int t = token[b];
+            const int t = token_val >= -1 ? token_val : token[b];
             const int cur = s[F_CUR];
             const bool remnant = cur < s[F_NCHORD];
             const int cp = remnant ? chord_pos[(size_t)b * ld_chord + cur] : -1;

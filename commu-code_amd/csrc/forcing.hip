@@ -24,16 +24,22 @@ __global__ __launch_bounds__(64) void forcing_pre_kernel(int* st, int* seq, int 
                                                          int max_iters, long long* tok, unsigned char* active,
                                                          unsigned char* keep, unsigned char* draw, float* uni, int* trace,
                                                          int ld_trace) {
-    forcing_pre_body(blockIdx.x, threadIdx.x, st, seq, ld_seq, chord_tok, chord_pos, ld_chord, wrong, utable, ld_u, max_iters,
+    int rec[F_COUNT];
+    if (threadIdx.x == 0) record_load(rec, st, blockIdx.x);
+    forcing_pre_body(blockIdx.x, threadIdx.x, rec, seq, ld_seq, chord_tok, chord_pos, ld_chord, wrong, utable, ld_u, max_iters,
                      tok, active, keep, draw, uni, trace, ld_trace);
+    if (threadIdx.x == 0) record_store(rec, st, blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void forcing_post_kernel(int* st, int* seq, int ld_seq, const int* __restrict__ chord_pos,
                                                           int ld_chord, unsigned char* wrong, const unsigned char* draw,
                                                           const int* token, int* live, int* klen, const unsigned char* keep,
                                                           int lmax) {
-    forcing_post_body(blockIdx.x, threadIdx.x, st, seq, ld_seq, chord_pos, ld_chord, wrong, draw, token, live, klen, keep,
+    int rec[F_COUNT];
+    if (threadIdx.x == 0) record_load(rec, st, blockIdx.x);
+    forcing_post_body(blockIdx.x, threadIdx.x, rec, seq, ld_seq, chord_pos, ld_chord, wrong, draw, token, live, klen, keep,
                       lmax);
+    if (threadIdx.x == 0) record_store(rec, st, blockIdx.x);
 }
 
 // One launch for the three per-sequence stages that follow the model step: sampling step -> book-keeping (post) -> the
@@ -57,16 +63,19 @@ struct LoopStageArgs {
 __global__ __launch_bounds__(64) void sample_post_pre_kernel(LoopStageArgs a) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 0] = wall_clock64();
-    sample_topk_body(b, lane, a.logits, a.ld, a.V, a.wrong, VOCAB, a.uni, a.draw, a.temperature, a.top_k, a.token,
-                     a.probs_out, a.ldp, a.top_p);
+    int rec[F_COUNT];                                  // the record travels through the three stages in lane 0's registers;
+    if (lane == 0) record_load(rec, a.st, b);          // its loads are in flight under the sampling step
+    const int drawn = sample_topk_body(b, lane, a.logits, a.ld, a.V, a.wrong, VOCAB, a.uni, a.draw, a.temperature, a.top_k,
+                                       a.token, a.probs_out, a.ldp, a.top_p);
     __syncthreads();
     if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 1] = wall_clock64();
-    forcing_post_body(b, lane, a.st, a.seq, a.ld_seq, a.chord_pos, a.ld_chord, a.wrong, a.draw, a.token, nullptr, a.klen,
-                      a.keep, a.lmax);
+    forcing_post_body(b, lane, rec, a.seq, a.ld_seq, a.chord_pos, a.ld_chord, a.wrong, a.draw, a.token, nullptr, a.klen,
+                      a.keep, a.lmax, drawn >= -1 ? drawn : -3);
     __syncthreads();
     if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 2] = wall_clock64();
-    forcing_pre_body(b, lane, a.st, a.seq, a.ld_seq, a.chord_tok, a.chord_pos, a.ld_chord, a.wrong, a.utable, a.ld_u,
+    forcing_pre_body(b, lane, rec, a.seq, a.ld_seq, a.chord_tok, a.chord_pos, a.ld_chord, a.wrong, a.utable, a.ld_u,
                      a.max_iters, a.tok, a.active, a.keep, a.draw, a.uni, a.step_trace, a.ld_trace);
+    if (lane == 0) record_store(rec, a.st, b);
     if (a.trace != nullptr && lane == 0) a.trace[b * 4 + 3] = wall_clock64();
 }
 
