@@ -22,46 +22,11 @@
 // Kernels: relattn_fwd (q-stationary), relattn_bwd_q (q-stationary: the AC part of dq, its column
 // sums, and dS indexed by distance for the dR / dq_BD GEMMs), relattn_bwd_kv (kv-stationary: dk,
 // dv), attn_delta, transpose_heads.
-#include "common.cuh"
-#include "commu_hip.h"
+#include "relattn_common.h"
 #include <stdlib.h>
 
 namespace {
 
-struct AttnArgs {
-    const bf16* q;      // rows i in [0,T)   : q  + (i*B+b)*ld_qkv + h*DH        (forward only)
-    const bf16* k;      // rows j in [0,K)   : k  + (j*B+b)*ld_qkv + h*DH
-    const bf16* v;
-    const bf16* rd;     // [K][ld_rd] distance-indexed, + h*DH
-    const float* u;     // r_w_bias [H][DH]
-    const float* vb;    // r_r_bias [H][DH]
-    const unsigned char* reset;   // [B] or null
-    bf16* qu2;          // [T*B][H*DH] (q+u)*scale*log2e : written by fwd (may be null), read by bwd
-    bf16* qv2;
-    const bf16* dout;   // dO rows like out, ld_o
-    const float* lse_in;
-    const float* delta;
-    const bf16* o_in;   // backward: forward output (or null); bwd_q then computes delta itself and writes it to `delta`
-    bf16* out;          // [T*B][ld_o]
-    float* lse;         // [B][H][T]
-    bf16* dq;           // [T*B][H*DH] AC part of dq
-    bf16* dk;           // rows like k, ld_dqkv
-    bf16* dv;
-    bf16* dsk;          // [H][T*B][ld_dsk]  dS indexed by distance d (zero-initialised by the caller)
-    float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
-    bf16* pbuf;         // P scratch [B*H][ceil(T/16)][ceil(K/64)][64 keys][16 rows]: written by bwd_q, read by bwd_kv2 (or null)
-    int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
-    int dsk_wedge;      // > 0: dsk is uninitialised; zero columns i+M+1 .. i+M+dsk_wedge of every row (band GEMM contract)
-    int dsk_tiled;      // != 0: dsk is stored as [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (band.hip)
-    int T, M, B, H;
-    int same_length, sshift;
-    float scale;
-    unsigned drop_seed, drop_thr;   // attention-probability dropout: 16-bit threshold (0: off), see DropLane
-    float drop_scale;
-};
-
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
 constexpr int PT = 16;      // pitch (elements) of a per-wave transposed tile [64 kv][16 rows]: 4 rows = 128 contiguous bytes per tr-read group
 
 template <int COLS>
@@ -148,32 +113,12 @@ __device__ __forceinline__ bool drop_keep16(const unsigned (&hw)[2], int reg, un
 __device__ __forceinline__ float bperm(int addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
-__device__ __forceinline__ bool is_masked(int i, int j, int M, int same_length, int sshift, bool rst) {
-    return (j > i + M) || (same_length && j <= i - sshift) || (rst && j < M);
-}
-// kv tile range visible from query rows [i0, i0+qrows-1]
-__device__ __forceinline__ void kv_range(const AttnArgs& a, int i0, int qrows, bool rst, int& jt_lo, int& jt_hi) {
-    const int K = a.T + a.M;
-    int jlo = rst ? a.M : 0;
-    if (a.same_length) jlo = max(jlo, i0 - a.sshift + 1);
-    jlo = max(jlo, 0);
-    const int jhi = min(K - 1, i0 + qrows - 1 + a.M);
-    jt_lo = jlo >> 6;
-    jt_hi = jhi >> 6;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Tile staging through registers with buffer loads: one SRD per operand, a per-thread byte offset
 // computed once, one v_add per load per tile; rows outside the tensor (kv rows >= K, band distances
 // d < 0 or d >= K) are outside the SRD's range and read as zero in hardware -- no clamps, no
 // branches.  Loads for tile t+1 are issued before tile t is computed and committed to LDS after it.
-typedef __amdgpu_buffer_rsrc_t srd_t;
-__device__ __forceinline__ srd_t make_srd(const void* p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)bytes, 0x00020000);
-}
-__device__ __forceinline__ bf16x8 buf_ld(srd_t r, unsigned byte_off) {
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
 template <int ROWS, int COLS, int NTHR = 256>
 struct Stager {
     static constexpr int CH = COLS / 8;
@@ -212,24 +157,6 @@ struct Stager {
 template <int NCH, int STEP>
 __device__ __forceinline__ int ring_row(int x, int t) { return ((((x >> 6) + STEP * t) % NCH) << 6) + (x & 63); }
 
-// Workgroups go to the 8 XCDs round-robin by linear id.  Hand every XCD whole (batch, head) pairs: all
-// tiles of a pair share K, V and the band (they hit in that XCD's L2), and the heavy and light tiles of
-// the causal triangle land on the same XCD, so the per-XCD work is balanced.  (A 3-D grid with the tile
-// index fastest puts tile t on XCD t % 8: 2.4x more work on XCD 0 than on XCD 7 at 16 tiles.)
-__device__ __forceinline__ void tile_coords(int ntile, int H, int B, int& tile, int& h, int& b) {
-    const int id = blockIdx.x, NP = H * B;
-    int pair;
-    if ((NP & 7) == 0) {
-        const int slot = id >> 3;
-        pair = (slot / ntile) * 8 + (id & 7);
-        tile = slot % ntile;
-    } else {
-        pair = id / ntile;
-        tile = id % ntile;
-    }
-    b = pair / H;
-    h = pair - b * H;
-}
 
 // =============================================================================================
 template <int DH, int NW, bool DROP>
@@ -478,13 +405,6 @@ __device__ __forceinline__ void row16_max4(float& x0, float& x1, float& x2, floa
         "v_max_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 }
-__device__ __forceinline__ void lds_dma16(srd_t srd, unsigned voff, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :: "s"(lds_dst), "v"(voff), "s"(srd) : "memory");
-}
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // STAG: the two halves of the workgroup (waves 0-3 / 4-7: query rows 0-63 / 64-127) run HALF A TILE apart, separated by
 // two barriers per key tile: while one half is in the matrix-heavy first half of a tile (band product, skew, QK^T) the
@@ -1579,8 +1499,11 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     // tiles at every shape of this model, so only NW = 4 is instantiated)
     dim3 grid((((d->T + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
-    static const int fwd_gen = getenv("COMMU_ATTN_FWD_GEN") ? atoi(getenv("COMMU_ATTN_FWD_GEN")) : 2;
-    if (d->DH == 64 && fwd_gen == 2) {          // second-generation kernel: 128 query rows per workgroup
+    // d_head 64: third generation (relattn3.hip).  Its attention-dropout mask is the second form (pairs along the
+    // keys): it is the default with dropout only once the backward kernels draw the same mask (COMMU_ATTN_MASK2).
+    static const int fwd_gen = getenv("COMMU_ATTN_FWD_GEN") ? atoi(getenv("COMMU_ATTN_FWD_GEN")) : 0;
+    if (d->DH == 64 && (fwd_gen == 3 || (fwd_gen == 0 && !drop))) return launch_relattn_fwd3(a, stream);
+    if (d->DH == 64 && (fwd_gen == 2 || fwd_gen == 0)) {          // second-generation kernel: 128 query rows per workgroup
         dim3 grid2((((d->T + 127) / 128 + 1) / 2) * d->H * d->B);
         static const int stag = getenv("COMMU_ATTN_FWD_STAG") ? atoi(getenv("COMMU_ATTN_FWD_STAG")) : 0;
         if (stag == 1) {
