@@ -2,8 +2,10 @@
 """Benchmark of the ComMU Transformer-XL training hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-one rank per GPU over RCCL.)  Prints ONE JSON line on rank 0.
+N > 1 without a torch.distributed environment: this process starts the N ranks ITSELF (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a child, before touching the GPU), relays rank 0's line
+and exits with the child's status; under `torch.distributed.run` (WORLD_SIZE set) it is one rank.  One rank per GPU over
+RCCL; fewer visible GPUs than N is an error, never a silent one-rank number.  Prints ONE JSON line on rank 0.
 
 Workload (BASELINE.json configs[1]): 6 layers, d_model 512, 8 heads (d_head 64), FFN 1024,
 tgt_len 1024, mem_len 0, 64 sequences per GPU (weak scaling), bf16 GEMM/attention operands with
@@ -552,6 +554,28 @@ def extra_rows(args, dev):
     return rows
 
 
+def launch_ranks(n, argv, popen=None, device_count=None):
+    """`bench.py --gpus n` outside torch.distributed.run: start the n ranks as ONE child (torch.distributed.run, which
+    spawns them), wait, return its exit status.  Nothing here initialises the GPU (torch.cuda.device_count() does not on
+    this image): the ranks are new processes, never an exec of a process that has touched the device.
+    popen / device_count: test hooks."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count() if device_count is None else device_count
+    if ndev < n:
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) visible; not running a smaller job under that name",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = (popen or subprocess.Popen)(cmd, env=env)
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -588,16 +612,19 @@ def main():
                     help="weight-gradient work on the main stream (default: a side stream)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
+        world = dist.get_world_size()                     # n_gpus of the line is what really runs
 
     scaling = "weak"
     if args.global_batch > 0:

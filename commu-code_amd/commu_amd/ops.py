@@ -79,15 +79,35 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float):
-    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests; relattn.hip DropLane).
-    Every 16x16 block (i>>4, j>>4) of a (batch, head) has a 32-bit key from the strong hash (scalar work in the
-    kernels); inside the block a cheap two-round 24-bit multiply hash of (row pair, column) gives one word per two
-    rows: low 16 bits -> even row, high 16 bits -> odd row, compared with round(p * 65536)."""
+def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float, version: int = 1):
+    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests).
+    version 1 (relattn.hip DropLane; every kernel of the 16x16-layout family, forward and backward): every 16x16 block
+    (i>>4, j>>4) of a (batch, head) has a 32-bit key from the strong hash (scalar work in the kernels); inside the block a
+    cheap two-round 24-bit multiply hash of (row pair, column) gives one word per two rows: low 16 bits -> even row, high
+    16 bits -> odd row, compared with round(p * 65536).
+    version 2 (relattn3.hip, commu_attn_fwd_generation(3)): 32x32 blocks (i>>5, j>>5) with three scalar keys; one mixed
+    index per (row, key pair) and one 24-bit multiply-add per key -- even and odd key use different constants --, the whole
+    32-bit word against round(p * 65536) << 16."""
     thr = max(1, int(p * 65536.0 + 0.5)) if p > 0 else 0
     out = torch.empty(B, H, T, K, dtype=torch.bool)
     rows = torch.arange(T, dtype=torch.int64)[:, None]
     cols = torch.arange(K, dtype=torch.int64)[None, :]
+    M32 = 0xFFFFFFFF
+    if version == 2:
+        blk = ((rows >> 5) << 16) | (cols >> 5)
+        xc = ((((rows & 31) << 4) | ((cols & 31) >> 1)) * 0xD2B74B) & M32
+        odd = (cols & 1).bool().expand(T, K)
+        for b in range(B):
+            for h in range(H):
+                key_bh = int(_mix32(torch.tensor((seed + (b * H + h) * 0x9E3779B1) & M32, dtype=torch.int64)))
+                k1 = _mix32k(blk, key_bh)
+                k2 = (k1 * 0x85EBCA6B + 0x6A09E667) & M32
+                k3 = (k1 * 0xC2B2AE35 + 0xBB67AE85) & M32
+                y = (xc + k1) & M32
+                y = (y ^ (y >> 12)) & 0xFFFFFF
+                w = torch.where(odd, (y * 0x85EBCB + k3) & M32, (y * 0x9E3779 + k2) & M32)
+                out[b, h] = w >= (thr << 16)
+        return out, 1.0 - thr / 65536.0
     blk = ((rows >> 4) << 16) | (cols >> 4)
     xc = ((((rows & 15) >> 1) << 4) | (cols & 15)) * 0xD2B74B
     for b in range(B):
@@ -102,6 +122,11 @@ def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float):
             half = (y >> (16 * (rows & 1))) & 0xFFFF
             out[b, h] = half >= thr
     return out, 1.0 - thr / 65536.0
+
+
+def attn_fwd_generation(gen: int) -> int:
+    """commu_attn_fwd_generation: 0 automatic, 2 / 3 force a forward kernel family for d_head 64; returns the previous value."""
+    return call("commu_attn_fwd_generation", int(gen))
 
 
 def _rowmajor2d(t: torch.Tensor, name: str):

@@ -1488,6 +1488,13 @@ extern "C" long long commu_attn_p_scratch_elems(int T, int M, int B, int H) {
     return (long long)B * H * ((T + 15) / 16) * ((T + M + 63) / 64) * 1024;
 }
 
+static int g_fwd_gen = 0;
+extern "C" int commu_attn_fwd_generation(int gen) {
+    const int prev = g_fwd_gen;
+    if (gen == 0 || gen == 2 || gen == 3) g_fwd_gen = gen;
+    return prev;
+}
+
 extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                                  hipStream_t stream) {
     if (d->T <= 0 || d->B <= 0) return 0;
@@ -1499,9 +1506,8 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     // tiles at every shape of this model, so only NW = 4 is instantiated)
     dim3 grid((((d->T + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
-    // d_head 64: third generation (relattn3.hip).  Its attention-dropout mask is the second form (pairs along the
-    // keys): it is the default with dropout only once the backward kernels draw the same mask (COMMU_ATTN_MASK2).
-    static const int fwd_gen = getenv("COMMU_ATTN_FWD_GEN") ? atoi(getenv("COMMU_ATTN_FWD_GEN")) : 0;
+    // d_head 64: third generation (relattn3.hip) unless the pass has attention dropout (commu_attn_fwd_generation)
+    const int fwd_gen = g_fwd_gen;
     if (d->DH == 64 && (fwd_gen == 3 || (fwd_gen == 0 && !drop))) return launch_relattn_fwd3(a, stream);
     if (d->DH == 64 && (fwd_gen == 2 || fwd_gen == 0)) {          // second-generation kernel: 128 query rows per workgroup
         dim3 grid2((((d->T + 127) / 128 + 1) / 2) * d->H * d->B);

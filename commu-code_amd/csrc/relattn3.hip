@@ -20,6 +20,7 @@
 // 64 keys.  Waves w and w + 4 share a SIMD and take row slices w and 7 - w, so every SIMD sees the same causal work.
 #include "relattn_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -57,10 +58,10 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 }
 
 constexpr int TILEB = 8192;                                   // [64 rows][64] bf16
-constexpr int OFF_K = 0, OFF_V = 2 * TILEB, OFF_R = 4 * TILEB, NRCH = 6;
+constexpr int OFF_K = 0, OFF_V = 2 * TILEB, OFF_R = 5 * TILEB, NRCH = 6;      // K x2, V x3, Rd ring
 constexpr int OFF_RING = OFF_R + NRCH * TILEB;
 constexpr int RINGB = 8832;                                   // per wave: rows of 64 fp32 at word 68 i + 4 (i >> 2)
-constexpr int LDS_FWD3 = OFF_RING + 8 * RINGB;                // 152 576 bytes
+constexpr int LDS_FWD3 = OFF_RING + 8 * RINGB;                // 160 768 bytes
 
 // 16-byte chunk c of row R of a [64][64] bf16 tile lives at chunk c ^ swz3(R): conflict-free for the ds_read_b128 of a
 // 32-row MFMA operand (lanes = rows) and for ds_read_b64_tr_b16 (4 rows x 4 chunks per 32 lanes)
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     LDS_AS char* const lds = (LDS_AS char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);                 // the later-dispatched half loses every arbitration otherwise
     const int ii = lane & 31, half = lane >> 5, r16 = lane & 15;
     const int s = w < 4 ? w : 11 - w;                          // row slice of this wave
     const int T = a.T, M = a.M, B = a.B, K = T + M;
@@ -106,6 +108,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int fa[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fa[ks] = ii * 128 + (((2 * ks + half) ^ swz3(ii)) << 4);
+    // ... of the K tile: accumulator row rho is key rho ^ 3 (the ring stores keys in DESCENDING column order so that the
+    // band producer's writes ascend with its registers; reversing the keys inside each quad makes the 16-byte ring reads
+    // land in register order again, and the V^T transpose reads below supply their rows reversed the same way)
+    int fk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fk[ks] = (ii ^ 3) * 128 + (((2 * ks + half) ^ swz3(ii ^ 3)) << 4);
     // V^T operand (32 features x 16 keys) by transpose reads: lane group (lane >> 4) & 1 covers features +16, each lane
     // supplies the address of 4 consecutive features of key row 4 half + 8 X + (r16 >> 2)  (+16 ks2, +32 u: immediates)
     int va[2][2];
@@ -113,23 +121,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
-            const int R = 4 * half + 8 * X + (r16 >> 2), col = 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (r16 & 3);
+            const int R = 4 * half + 8 * X + 3 - (r16 >> 2), col = 32 * dt + 16 * ((lane >> 4) & 1) + 4 * (r16 & 3);
             va[dt][X] = R * 128 + ((((col >> 3) ^ swz3(R))) << 4) + (col & 7) * 2;
         }
     // the wave's BD ring
     const int m4 = ii & 3;
     const int ringb = OFF_RING + w * RINGB;
     const int rowb = ringb + 4 * (68 * ii + 4 * (ii >> 2));
-    const int c0 = 63 - 4 * half + m4;                         // column of distance offset 0 of a parity-0 block: 59 .. 66
-    const int aw = rowb + 4 * (c0 - 59);                       // + 4 (27 - dr) (+128 for parity 0), dr = (r & 3) + 8 (r >> 2)
+    const int c0 = 63 - 4 * half + m4;                         // un-mirrored column of distance offset 0 of a form-0 block: 59 .. 66
+    // mirrored ring columns (63 - column): a block's register r (distance offset dr + 4 half, dr = (r & 3) + 8 (r >> 2))
+    // goes to column 63 - c0 + dr of form 0, + 32 of form 1; form 0 wraps for dr < c0 - 63 (dr <= 2)
+    const int aw = rowb + 4 * (63 - c0);
     int aw0[3];
 #pragma unroll
-    for (int dr = 0; dr < 3; ++dr) aw0[dr] = rowb + 4 * ((c0 - dr) & 63);      // parity 0, dr < 3: may wrap
-    int ar[2][4];
+    for (int dr = 0; dr < 3; ++dr) aw0[dr] = rowb + 4 * (63 - ((c0 - dr) & 63));
+    int ar[2][4];                                              // quad q of a sub-tile of parity u: keys 8q + 4 half + 3 .. + 0
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ar[u][q] = rowb + 4 * ((32 * u + 8 * q + 4 * half - 4 * (ii >> 2)) & 63);
+        for (int q = 0; q < 4; ++q) ar[u][q] = rowb + 4 * (60 - ((32 * u + 8 * q + 4 * half - 4 * (ii >> 2)) & 63));
 
     const unsigned key_bh = DROP ? mix32(salted(a.drop_seed) + (unsigned)(b * a.H + h) * 0x9E3779B1u) : 0u;
     const unsigned xl = (unsigned)((ii << 4) | (2 * half)) * DROP_C1;
@@ -156,14 +166,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int slot = (c + 600) % NRCH;
             lds_dma16(srdR, (unsigned)(E + 64 * c + drow) * rdb + dchunk, ldsw + (unsigned)(OFF_R + slot * TILEB));
         };
-        auto stage_kv = [&](int jt, int buf) {
-            const unsigned off = (unsigned)(jt * 64 + drow) * rsb + dchunk;
-            lds_dma16(srdK, off, ldsw + (unsigned)(OFF_K + buf * TILEB));
-            lds_dma16(srdV, off, ldsw + (unsigned)(OFF_V + buf * TILEB));
+        auto stage_kv = [&](int t) {                              // tile t of this pass: K double-, V triple-buffered
+            const unsigned off = (unsigned)((jt_lo + t) * 64 + drow) * rsb + dchunk;
+            lds_dma16(srdK, off, ldsw + (unsigned)(OFF_K + (t & 1) * TILEB));
+            lds_dma16(srdV, off, ldsw + (unsigned)(OFF_V + (t % 3) * TILEB));
         };
 #pragma unroll
         for (int c = -1; c <= 4; ++c) stage_rd(c);
-        stage_kv(jt_lo, 0);
+        stage_kv(0);
 
         bf16x8 qu[4], qv[4];
         {
@@ -173,12 +183,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 raw = ld_bf16x8(qp + 16 * ks + 8 * half);
+                const int f0 = h * 64 + 16 * ks + 8 * half;       // (r_w_bias / r_r_bias rows of 64 floats: 32-byte pieces)
+                const f32x4 u0 = *(const f32x4*)(a.u + f0), u1 = *(const f32x4*)(a.u + f0 + 4);
+                const f32x4 v0 = *(const f32x4*)(a.vb + f0), v1 = *(const f32x4*)(a.vb + f0 + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int f = h * 64 + 16 * ks + 8 * half + e;
                     const float x = bf2f(raw[e]);
-                    qu[ks][e] = f2bf((x + a.u[f]) * c2);
-                    qv[ks][e] = f2bf((x + a.vb[f]) * c2);
+                    qu[ks][e] = f2bf((x + (e < 4 ? u0[e & 3] : u1[e & 3])) * c2);
+                    qv[ks][e] = f2bf((x + (e < 4 ? v0[e & 3] : v1[e & 3])) * c2);
                 }
                 if (a.qu2 != nullptr && irow < T) {
                     const size_t off = ((size_t)irow * B + b) * (a.H * 64) + h * 64 + 16 * ks + 8 * half;
@@ -192,19 +204,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
-        float mrow = -3.0e38f, lsum = 0.f;
-        int fak[4], vak[2][2];                                    // K / V fragment addresses of the current buffer
+        float mrow = -3.0e38f, lsA = 0.f, lsB = 0.f;
+        int fak[4], vak[2][2];                                    // K / V fragment addresses of the current buffers
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fak[ks] = OFF_K + fa[ks];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int X = 0; X < 2; ++X) vak[dt][X] = OFF_V + va[dt][X];
+        for (int ks = 0; ks < 4; ++ks) fak[ks] = OFF_K + fk[ks];
 
-        // band block hc: distances E + 32 hc .. + 31 against the wave's 32 queries -> BD ring (key-indexed)
-        auto band_block = [&](int hc, int u) {
-            const int chunk = hc >> 1;
-            const int rbase = OFF_R + ((chunk + 600) % NRCH) * TILEB + (hc & 1) * 4096;
+        // ---- pieces of a sub-tile -----------------------------------------------------------------------------------
+        // band block of sub-tile m: distances E + 32 (s - m + 1) .. + 31 against the wave's 32 queries -> BD ring; its ring
+        // columns are (c0 - dr) for even m - 1 ("form 0") and (c0 - 32 - dr) for odd
+        auto band_rbase = [&](int m) {
+            const int hc = s - m + 1;
+            return OFF_R + (((hc >> 1) + 600) % NRCH) * TILEB + (hc & 1) * 4096;
+        };
+        auto band_write = [&](const f32x16& acc, int form, int r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (form == 0 && dr < 3) *(LDS_AS float*)(lds + aw0[dr]) = acc[r];
+            else *(LDS_AS float*)(lds + aw + 4 * dr + (form == 0 ? 0 : 128)) = acc[r];
+        };
+        auto band_block = [&](int m, int form) {                  // un-pipelined (prologue)
+            const int rbase = band_rbase(m);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -212,32 +230,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int ks = 0; ks < 4; ++ks)
                 acc = mfma32(*(const LDS_AS bf16x8*)(lds + rbase + fa[ks]), qv[ks], acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = (r & 3) + 8 * (r >> 2);
-                if (u == 0 && dr < 3) *(LDS_AS float*)(lds + aw0[dr]) = acc[r];
-                else *(LDS_AS float*)(lds + aw + 4 * (27 - dr) + (u == 0 ? 128 : 0)) = acc[r];
-            }
+            for (int r = 0; r < 16; ++r) band_write(acc, form, r);
         };
-
-        auto subtile = [&](int t, int u) {
-            const int jb = 64 * (jt_lo + t) + 32 * u;
-            f32x16 S;
+        auto ring_read = [&](f32x16& S, int par) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const LDS_AS f32x4*)(lds + ar[u][q]);
+                const f32x4 v = *(const LDS_AS f32x4*)(lds + ar[par][q]);
                 S[4 * q + 0] = v[0]; S[4 * q + 1] = v[1]; S[4 * q + 2] = v[2]; S[4 * q + 3] = v[3];
             }
+        };
+        auto need_mask = [&](int m) {
+            const int jb = 64 * jt_lo + 32 * m;
+            return (jb + 31 > iw + M) || (a.same_length && jb <= iw + 31 - a.sshift) || (rst && jb < M);
+        };
+        auto apply_mask = [&](f32x16& S, int m) {
+            const int jb = 64 * jt_lo + 32 * m, i = iw + ii;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                S = mfma32(*(const LDS_AS bf16x8*)(lds + fak[ks] + 4096 * u), qu[ks], S);
-            const bool need_mask = (jb + 31 > iw + M) || (a.same_length && jb <= iw + 31 - a.sshift) || (rst && jb < M);
-            if (need_mask) {
-                const int i = iw + ii;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (is_masked(i, jb + (r & 3) + 8 * (r >> 2) + 4 * half, M, a.same_length, a.sshift, rst)) S[r] = -INFINITY;
-            }
-            // online softmax in the log2 domain; the other half-wave holds the other 16 keys of the same query
+            for (int r = 0; r < 16; ++r)
+                if (is_masked(i, jb + 3 - (r & 3) + 8 * (r >> 2) + 4 * half, M, a.same_length, a.sshift, rst)) S[r] = -INFINITY;
+        };
+        // running maximum (log2 domain) over the finished score tile S; O and the partial sums follow when it grows
+        auto fold_max = [&](const f32x16& S) {
             float mx = max3f(S[0], S[1], S[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = max3f(mx, S[r], S[r + 1]);
@@ -247,80 +260,184 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (__any(mnew > mrow)) {
                 const float al = __builtin_amdgcn_exp2f(mrow - mnew);
                 mrow = mnew;
-                lsum *= al;
+                lsA *= al;
+                lsB *= al;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) O[dt][r] *= al;
             }
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(S[r] - mrow);
-                lsum += p[r];                                     // the normaliser is the un-dropped sum
-            }
-            if (DROP) {                                           // 1/(1-p) is applied to O at the end
-                const unsigned k1 = mix32k(((unsigned)(iw >> 5) << 16) | (unsigned)(jb >> 5), key_bh);
-                const unsigned k2 = k1 * 0x85EBCA6Bu + 0x6A09E667u, k3 = k1 * 0xC2B2AE35u + 0xBB67AE85u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        unsigned y = xl + ((unsigned)(4 * q + pr) * DROP_C1 + k1);
-                        y ^= y >> 12;
-                        const unsigned w0 = (y & 0xFFFFFFu) * DROP_C2 + k2, w1 = (y & 0xFFFFFFu) * DROP_C3 + k3;
-                        p[4 * q + 2 * pr] = w0 >= thr32 ? p[4 * q + 2 * pr] : 0.f;
-                        p[4 * q + 2 * pr + 1] = w1 >= thr32 ? p[4 * q + 2 * pr + 1] : 0.f;
-                    }
-            }
-            bf16x8 pf[2];
-#pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[ks2][e] = f2bf(p[8 * ks2 + e]);
-#pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x4 lo = tr8(vak[dt][0] + 2048 * ks2 + 4096 * u), hi = tr8(vak[dt][1] + 2048 * ks2 + 4096 * u);
-                    bf16x8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3]; vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    O[dt] = mfma32(vf, pf[ks2], O[dt]);
-                }
         };
 
+        // One pipelined step n (u = n & 1): softmax arithmetic of sub-tile n (scores Sc, complete and folded into mrow) in
+        // eight slices of two keys, each slice behind one MFMA of sub-tile n+1's score product (ring values as the initial
+        // accumulator) or of the band block of sub-tile n+2; then P(n) . V with the maximum of sub-tile n+1 folded in under
+        // its MFMAs.  FULL: sub-tiles n+1 and n+2 exist (no tests inside).
+        int rb_step = band_rbase(2);                              // Rd half-chunk of the block step n computes (sub-tile n + 2)
+        auto rb_advance = [&]() {                                 // one half-chunk (32 distances) down, ring of NRCH chunks
+            rb_step -= 4096;
+            if (rb_step < OFF_R) rb_step += NRCH * TILEB;
+        };
+        auto step = [&](auto UC, auto FC, f32x16& Sc, f32x16& Sn, int n) {
+            constexpr int u = decltype(UC)::value;
+            constexpr bool FULL = decltype(FC)::value;
+            const bool h1 = FULL || (n + 1 < nsub_w), h2 = FULL || (n + 2 < nsub_w);
+            bf16x8 kf[4], rf[4];
+            f32x16 acc;
+            if (h1) {
+                ring_read(Sn, u ^ 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const LDS_AS bf16x8*)(lds + fak[ks] + 4096 * (u ^ 1));
+            }
+            if (h2) {
+                const int rbase = rb_step;                        // == band_rbase(n + 2), kept incrementally (tile loops)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) rf[ks] = *(const LDS_AS bf16x8*)(lds + rbase + fa[ks]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            unsigned k1 = 0, k2 = 0, k3 = 0;
+            if (DROP) {
+                k1 = mix32k(((unsigned)(iw >> 5) << 16) | (unsigned)(2 * jt_lo + n), key_bh);
+                k2 = k1 * 0x85EBCA6Bu + 0x6A09E667u;
+                k3 = k1 * 0xC2B2AE35u + 0xBB67AE85u;
+            }
+            unsigned pw[8];
+            auto sm = [&](int k) {                                // keys 2k, 2k+1 of the quad layout: exp, sums, dropout, bf16 pair
+                float e0 = __builtin_amdgcn_exp2f(Sc[2 * k] - mrow), e1 = __builtin_amdgcn_exp2f(Sc[2 * k + 1] - mrow);
+                lsA += e0;                                        // the normaliser is the un-dropped sum
+                lsB += e1;
+                if (DROP) {                                       // 1/(1-p) is applied to O at the end
+                    // registers 2k, 2k+1 hold keys 8 (k >> 1) + 4 half + 3 - 2 (k & 1) and the one below it: key pair
+                    // 4 (k >> 1) + 2 half + 1 - (k & 1), odd key first
+                    unsigned y = xl + ((unsigned)(4 * (k >> 1) + 1 - (k & 1)) * DROP_C1 + k1);
+                    y ^= y >> 12;
+                    const unsigned w0 = (y & 0xFFFFFFu) * DROP_C2 + k2, w1 = (y & 0xFFFFFFu) * DROP_C3 + k3;
+                    e0 = w1 >= thr32 ? e0 : 0.f;
+                    e1 = w0 >= thr32 ? e1 : 0.f;
+                }
+                // (the compiler's own v_cvt_pk_bf16_f32: it knows the wait state a transcendental result needs)
+                pw[k] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+            };
+            bf16x4 vt[2][2][2];                                   // [ks2][dt][X]
+            auto vread = [&](int dt) {
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) vt[ks2][dt][X] = tr8(vak[dt][X] + 2048 * ks2 + 4096 * u);
+            };
+            auto pv = [&](int ks2, int dt) {
+                bf16x8 vf;
+                const bf16x4 lo = vt[ks2][dt][0], hi = vt[ks2][dt][1];
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3]; vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                u32x4 pq;
+                pq[0] = pw[4 * ks2]; pq[1] = pw[4 * ks2 + 1]; pq[2] = pw[4 * ks2 + 2]; pq[3] = pw[4 * ks2 + 3];
+                O[dt] = mfma32(vf, __builtin_bit_cast(bf16x8, pq), O[dt]);
+            };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+            SB();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (h1) Sn = mfma32(kf[ks], qu[ks], Sn);
+                sm(2 * ks);
+                if (ks == 1) vread(0);
+                SB();
+                if (h2) acc = mfma32(rf[ks], qv[ks], acc);
+                sm(2 * ks + 1);
+                if (ks == 1) vread(1);
+                SB();
+            }
+            pv(0, 0);
+            SB();
+            if (!FULL && h1 && need_mask(n + 1)) apply_mask(Sn, n + 1);      // (a straight-line step never meets a mask)
+            SB();
+            pv(0, 1);
+            if (h2) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) band_write(acc, u ^ 1, r);
+            }
+            SB();
+            pv(1, 0);
+            if (h2) {
+#pragma unroll
+                for (int r = 8; r < 16; ++r) band_write(acc, u ^ 1, r);
+            }
+            SB();
+            pv(1, 1);
+            if (h1) fold_max(Sn);
+#undef SB
+        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (active) {                                             // distances of the first sub-tile: two blocks
-            band_block(s + 2, 0);
-            band_block(s + 1, 1);
+        if (nsub_w > 0) {                                         // distances of sub-tile 0: two blocks
+            band_block(-1, 0);
+            band_block(0, 1);
         }
-        for (int t = 0; t < NT; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t has landed
-            __builtin_amdgcn_s_barrier();                         // ... everybody's has; tile t-1 is no longer read
-            if (t + 1 < NT) {
-                stage_kv(jt_lo + t + 1, (t + 1) & 1);
-                stage_rd(-2 - t);
-            }
+        __builtin_amdgcn_s_barrier();                             // chunk 4 (first blocks of the top waves) is free
+        if (NT > 1) {
+            stage_kv(1);
+            stage_rd(-2);
+        }
+        f32x16 SA, SB_;
+        if (nsub_w > 0) {                                         // scores of sub-tile 0, then the block of sub-tile 1 (it
+            ring_read(SA, 0);                                     // overwrites ring columns sub-tile 0 has just read)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int n = 2 * t + u;
-                if (n < nsub_w) {
-                    subtile(t, u);
-                    if (n + 1 < nsub_w) band_block(s - u - 2 * t, u);      // the 32 distances the next sub-tile adds
-                }
-            }
+            for (int ks = 0; ks < 4; ++ks) SA = mfma32(*(const LDS_AS bf16x8*)(lds + fak[ks]), qu[ks], SA);
+            if (nsub_w > 1) band_block(1, 0);
+            if (need_mask(0)) apply_mask(SA, 0);
+            fold_max(SA);
+        }
+        // barrier b_t sits between steps 2t and 2t+1: tile t+1 has landed (K of its first half is read by step 2t+1), tile
+        // t+2 may overwrite K(t) (last read by step 2t), V(t-1) and Rd chunk 3-t (last read by step 2t).
+        // Two loops over the tiles with the same barrier sequence: first the tiles whose steps all have two successors
+        // (straight-line bodies), then the wave's last tiles with tests inside (one instance of each step body per loop,
+        // so the accumulators stay where they are across iterations).
+        // (masks: only the causal edge, i.e. the sub-tiles from m0 on, when there are no reset / same_length masks)
+        const int m0 = max(0, ((iw + M - 64 * jt_lo - 31) >> 5) + 1);
+        const int t_full = (rst || a.same_length) ? 0 : min(NT, max(0, min((nsub_w - 2) >> 1, (m0 - 1) >> 1)));
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fak[ks] ^= TILEB;
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int X = 0; X < 2; ++X) vak[dt][X] = OFF_V + va[dt][X];
+        int vbuf = 0;                                             // V buffer of the current tile (t % 3)
+        auto tile_end = [&]() {                                   // V fragments of the next tile: next of the three buffers
+            const int d = vbuf == 2 ? -2 * TILEB : TILEB;
+            vbuf = vbuf == 2 ? 0 : vbuf + 1;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int X = 0; X < 2; ++X) vak[dt][X] ^= TILEB;
+                for (int X = 0; X < 2; ++X) vak[dt][X] += d;
+        };
+        auto tile_mid = [&](int t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < NT) {
+                stage_kv(t + 2);
+                stage_rd(-3 - t);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fak[ks] ^= TILEB;      // K fragments now come from tile t+1
+        };
+        for (int t = 0; t < t_full; ++t) {
+            step(std::integral_constant<int, 0>{}, std::true_type{}, SA, SB_, 2 * t);
+            rb_advance();
+            tile_mid(t);
+            step(std::integral_constant<int, 1>{}, std::true_type{}, SB_, SA, 2 * t + 1);
+            rb_advance();
+            tile_end();
+        }
+        for (int t = t_full; t < NT; ++t) {
+            if (2 * t < nsub_w) step(std::integral_constant<int, 0>{}, std::false_type{}, SA, SB_, 2 * t);
+            rb_advance();
+            tile_mid(t);
+            if (2 * t + 1 < nsub_w) step(std::integral_constant<int, 1>{}, std::false_type{}, SB_, SA, 2 * t + 1);
+            rb_advance();
+            tile_end();
         }
         // epilogue: normalise, O^T through the wave's ring area as [32 rows][64] bf16 (chunk c of row r at c ^ (r & 7)),
         // out as whole 128-byte rows; lse
         if (active) {
-            const float l = xhalf_sum(lsum);
+            const float l = xhalf_sum(lsA + lsB);
             const float inv = (DROP ? a.drop_scale : 1.f) / l;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -352,3 +469,4 @@ int launch_relattn_fwd3(const AttnArgs& a, hipStream_t stream) {
     COMMU_LAUNCH_CHECK();
     return 0;
 }
+

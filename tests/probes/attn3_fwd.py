@@ -10,6 +10,7 @@ HD, K = H * DH, T + M
 
 def run(drop):
     from commu_amd import ops
+    ops.attn_fwd_generation(int(os.environ.get("COMMU_ATTN_FWD_GEN", "0")))
     dev = "cuda"
     g = torch.Generator().manual_seed(1)
     qkv = (torch.randn(K * B, 3 * HD, generator=g) * 0.7).to(torch.bfloat16).to(dev)
@@ -29,7 +30,7 @@ def run(drop):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     gf = 6.0 * (M + (T + 1) / 2) * HD * T * B / 1e9
-    print(f"gen {os.environ.get('COMMU_ATTN_FWD_GEN')} drop {drop}: {us:8.1f} us  {gf / us * 1e-3:6.1f} TFLOP/s"
+    print(f"gen {os.environ.get('COMMU_ATTN_FWD_GEN')} drop {drop}: {us:8.1f} us  {gf / us * 1e3:6.1f} TFLOP/s"
           f"  out sum {float(out.float().abs().sum()):.6e} lse sum {float(lse.sum()):.6e}", flush=True)
     if drop == 0.0:
         torch.save((out.cpu(), lse.cpu()), f"/tmp/attn3_out_gen{os.environ.get('COMMU_ATTN_FWD_GEN')}.pt")

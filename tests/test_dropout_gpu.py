@@ -147,6 +147,39 @@ def test_attention_dropout_fwd_bwd_exact_mask(case, store_p):
     assert relerr(drd, rdl.grad) < tol and relerr(du, ul.grad) < tol and relerr(dvb, vl.grad) < tol
 
 
+@pytest.mark.parametrize("case", [(64, 0, 2, 2), (130, 0, 1, 1), (200, 70, 3, 2), (300, 33, 2, 1)])
+def test_attention_dropout_generation3_forward_exact_mask(case):
+    """relattn3.hip with attention dropout (commu_attn_fwd_generation(3); mask form 2, ops.attn_dropout_keep_mask(version=2))
+    against the oracle with the same mask injected.  Forward only: no backward kernel draws that mask yet."""
+    from commu_amd import ops
+    T, M, B, H = case
+    DH = 64
+    K, HD, p, seed = T + M, H * DH, 0.2, 99173
+    g = torch.Generator().manual_seed(5)
+    qkv = bf(torch.randn(K * B, 3 * HD, generator=g) * 0.7)
+    rd = bf(torch.randn(K, HD, generator=g) * 0.7)
+    u, vb = torch.randn(HD, generator=g) * 0.3, torch.randn(HD, generator=g) * 0.3
+    keep, pkeep = ops.attn_dropout_keep_mask(seed, B, H, T, K, p, version=2)
+    assert abs(float(keep.float().mean()) - pkeep) < 0.02
+    qf = qkv.float()
+    r = rd.float().view(K, H, DH).flip(0)
+    S = X.rel_attention_scores(qf[M * B:, :HD].reshape(T, B, H, DH), qf[:, HD:2 * HD].reshape(K, B, H, DH), r,
+                               u.view(H, DH), vb.view(H, DH)) / math.sqrt(DH)
+    S = S.masked_fill(X.attn_mask(T, M, B, None, False, M)[:, None], float("-inf"))
+    A = torch.softmax(S, 3) * keep / pkeep
+    ref = torch.einsum("bnij,jbnd->ibnd", A, qf[:, 2 * HD:].reshape(K, B, H, DH)).reshape(T * B, HD)
+    gq = qkv.to(DEV)
+    prev = ops.attn_fwd_generation(3)
+    try:
+        out, lse, _ = ops.relattn_fwd(gq[M * B:, :HD], gq[:, HD:2 * HD], gq[:, 2 * HD:], rd.to(DEV), u.to(DEV), vb.to(DEV),
+                                      None, T, M, B, H, DH, False, M, drop_p=p, drop_seed=seed)
+        torch.cuda.synchronize()
+    finally:
+        ops.attn_fwd_generation(prev)
+    assert relerr(out, ref) < 1.5e-2
+    assert float((lse.cpu() - torch.logsumexp(S, 3)).abs().max()) < 6e-3          # the normaliser is the un-dropped sum
+
+
 def test_model_train_mode_matches_oracle_with_same_masks(golden_dir):
     """Whole model in train() mode (dropout 0.1 / attention dropout 0.1) vs the oracle with the very
     same masks injected at the reference's nn.Dropout sites."""

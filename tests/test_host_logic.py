@@ -327,3 +327,27 @@ def test_bench_launch_mode_defaults():
     assert bench.passes_of(default) == 1 and not bench.auto_graph(default)
     assert bench.passes_of(ns(batch_chunk=4, merge_chunks=False)) == 4
     assert bench.passes_of(ns(tgt_len=2048, batch_per_gpu=64, batch_chunk=2)) == 2          # 131 072 tokens: the loop
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no torch.distributed environment starts ONE torch.distributed.run child for N ranks
+    on 127.0.0.1 and returns its status; fewer visible GPUs than N is an error (never a one-rank number called N)."""
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None):
+            seen["cmd"], seen["env"] = cmd, env
+
+        def wait(self):
+            return 7
+
+    rc = bench.launch_ranks(4, ["--gpus", "4", "--steps", "3"], popen=FakeProc, device_count=8)
+    assert rc == 7                                              # the child's status is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+    seen.clear()
+    assert bench.launch_ranks(2, ["--gpus", "2"], popen=FakeProc, device_count=1) != 0 and not seen      # too few GPUs: no launch
