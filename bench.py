@@ -256,7 +256,7 @@ def kernel_source_hash():
     measured on (tests/probes/pmc_traffic.py stamps the same hash into the profile)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("relattn.hip", "common.cuh"):
+    for name in ("relattn.hip", "relattn_common.h", "common.h"):
         with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -26,7 +26,7 @@ def sources():
 
 
 def newest_header():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(ROOT, "include", "commu_hip.h"))
     return max(os.path.getmtime(h) for h in hs)
 

@@ -131,6 +131,15 @@ class GradReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return [float(x) for x in t.cpu()]
 
+    def all_ok(self, ok: bool, device=None) -> bool:
+        """True iff `ok` holds on EVERY rank (one MIN all-reduce): for decisions all ranks must take together, e.g.
+        replayed graphs against eager steps, whose gradient exchanges issue different collectives."""
+        if self.world == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
     def barrier(self):
         if self.world > 1:
             dist.barrier(group=self.group)

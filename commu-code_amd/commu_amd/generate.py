@@ -326,6 +326,9 @@ class ForcedDecoder:
         if n_cond + 1 > self.n_ctx_max or any(len(m) != n_cond for m in encoded_metas):
             raise CommuHipError("encoded_meta: every sequence needs the same number (<= 15) of conditioning tokens")
         self.n_cond = n_cond
+        self._last_load = (encoded_metas, input_datas, uniforms)
+        if getattr(self.state, "t_err", None) is not None:
+            self.state.t_err.zero_()          # (a hand-off timeout of an earlier request must not fail this one)
         ctx = torch.tensor([[0] + list(m[:n_cond - 1]) for m in encoded_metas], dtype=torch.long).t().contiguous()
         self.state.kc.zero_()
         self.state.vc.zero_()
@@ -416,6 +419,19 @@ class ForcedDecoder:
                 self.body_pre()
 
     def run(self, use_graph: bool = True):
+        try:
+            self._run(use_graph)
+        except CommuHipError:
+            # a layer-tail launch gave up at a hand-off (e.g. the GPU was shared and its workgroups were not co-resident):
+            # generate the request again on the chain of per-Linear launches instead of failing it
+            if not self.state.tail_ok or getattr(self, "_last_load", None) is None:
+                raise
+            self.state.tail_ok = False
+            self.graph = None
+            self.load(*self._last_load)
+            self._run(use_graph)
+
+    def _run(self, use_graph: bool = True):
         if use_graph and self.graph is None:
             self.build_graph()
         self.pre()                                          # decision of the first iteration
@@ -546,5 +562,10 @@ class BatchedGenerator:
                 out = got
         if out is None:                        # max_attempts exhausted: whatever was accepted, in attempt order
             out = [results[a] for a in sorted(results) if results[a] is not False][:need]
-        dec.state.check()
+        try:
+            dec.state.check()
+        except CommuHipError:
+            dec.state.tail_ok, dec.graph = False, None          # later requests on this decoder: per-Linear launches
+            dec.state.t_err.zero_()
+            raise
         return out, started

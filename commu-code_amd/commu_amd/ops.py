@@ -41,14 +41,14 @@ def _mix32k(x, key):
     x = x & 0xFFFFFFFF
     x = x ^ (x >> 16)
     x = (x * 0x7feb352d) & 0xFFFFFFFF
-    x = x ^ key                               # the key enters between the two multiply rounds (common.cuh mix32k)
+    x = x ^ key                               # the key enters between the two multiply rounds (common.h mix32k)
     x = x ^ (x >> 15)
     x = (x * 0x846ca68b) & 0xFFFFFFFF
     return x ^ (x >> 16)
 
 
 def dropout_keep_mask(seed: int, n: int, p: float, device="cpu"):
-    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests; common.cuh drop_keep)."""
+    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests; common.h drop_keep)."""
     key = int(_mix32(torch.tensor(int(seed) & 0xFFFFFFFF, dtype=torch.int64)))
     x = _mix32k(torch.arange(n, dtype=torch.int64, device=device), key)
     thr = min(int(p * 4294967296.0), 4294967295) if p > 0 else 0

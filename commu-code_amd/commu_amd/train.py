@@ -111,10 +111,12 @@ class Trainer:
         for i in range(chunk):
             d, t, r = data_chunks[i].contiguous(), target_chunks[i].contiguous(), reset_chunks[i].contiguous()
             loss, new_mems = model(d, t, r, self.mems[i])
-            if self._graphs is not None and self._graph_state["mems"][i] is not None and new_mems is not None \
-                    and new_mems.shape == self._graph_state["mems"][i].shape:
-                self._graph_state["mems"][i].copy_(new_mems)      # an eager step between replays: the graph's buffers stay current
-                new_mems = self._graph_state["mems"][i]
+            if self._graphs is not None and self._graph_state["mems"][i] is not None and new_mems is not None:
+                if new_mems.shape == self._graph_state["mems"][i].shape:
+                    self._graph_state["mems"][i].copy_(new_mems)  # an eager step between replays: the graph's buffers stay current
+                    new_mems = self._graph_state["mems"][i]
+                else:                                             # another memory shape: the captured step is stale
+                    self._graphs, self._graph_state, self._graph_key = None, None, None
             self.mems[i] = new_mems
             if groups > 1:
                 loss, nll_sum = masked_mean_groups(loss, t, self.pad_id, groups)
@@ -269,15 +271,25 @@ class Trainer:
         from . import ops
         cfg, model = self.cfg, self.model
         if self._graphs is None:
+            err = None
             try:
                 self._capture(data, target, reset_mems)
             except Exception as exc:                          # capture refused: stay eager (same process, no re-exec)
-                self.graph_failed = f"{type(exc).__name__}: {exc}"
-                self._graphs = None
+                err = f"{type(exc).__name__}: {exc}"
+            # the decision is COLLECTIVE: a rank that fell back alone would run the overlapped bucket exchange of the
+            # eager step against the other ranks' single post-replay exchange (different collectives: a hang)
+            if self.reducer is not None:
+                ok_all = self.reducer.all_ok(err is None, device=data.device)
+                if not ok_all and err is None:
+                    err = "graph capture failed on another rank"
+            if err is not None:
+                self.graph_failed = err
+                self._graphs, self._graph_state = None, None
                 torch.cuda.synchronize()
                 return self.step(data, target, reset_mems, batch_token_num)
-            # hand the live memories to the graph: from now on they live in its static buffers
-            self.mems = self._graph_state["mems"]
+            # hand the live memories to the graph: from now on they live in its static buffers (the list is the
+            # trainer's own: an eager step may rebind its entries without touching the graph's)
+            self.mems = list(self._graph_state["mems"])
         st = self._graph_state
         fl = model._flat
         if fl.get("shadow_ready") is not None:                # an EAGER step ran since the last replay: its transposed

@@ -16,7 +16,7 @@
 // are XOR-swizzled so both the transpose reads and the ds_read_b128 of the dSk image are conflict-free.
 // The kernel is HBM-bound (the chip streams dSk at ~5 TB/s = 32 KB per CU every ~3700 cycles; the MFMA work of a
 // chunk is ~1000 cycles), so the pipeline is a plain two-stage one: stage next, compute current, one barrier per chunk.
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
 #include <stdlib.h>
 

@@ -12,7 +12,7 @@
 //
 //  kv_append : cache[b][klen[b]] = (k, v) of the new token (active sequences only)
 //  decode_attn: one workgroup per (b, h): scores lane-per-key, softmax in LDS, P.V lane-per-feature
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
 
 namespace {

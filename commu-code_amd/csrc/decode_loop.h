@@ -1,7 +1,7 @@
 // Per-sequence stages of the decode loop iteration as device functions (one 64-lane wave per sequence), shared by the
 // stand-alone kernels (sample.hip, forcing.hip) and the fused sample -> post -> pre launch (forcing.hip).
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

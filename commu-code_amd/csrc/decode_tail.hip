@@ -24,7 +24,7 @@
 // Operands go straight from global memory into MFMA fragments (as in the skinny kernel): the four waves split K, the
 // partial tiles are added through LDS.  The weights, biases and LayerNorm parameters of phase p + 1 are requested before
 // the wait that ends phase p, so that the wait hides their latency.
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
 #include <string.h>
 

@@ -2,7 +2,7 @@
 // sinusoid table, LayerNorm fwd/bwd, column sums (bias grads), log-softmax + NLL fwd/bwd,
 // grad-norm + clipped Adam, bf16 shadow cast / transpose, XL-memory window copy.
 // One wave (64 lanes) per row wherever a row reduction is needed; 16-byte accesses.
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
 
 namespace {

@@ -13,7 +13,7 @@
 //                        drawn -> reject, remember it, redo | EOS with chords left -> force position / bar | bar
 //                        with no chords left -> force EOS | else append.
 // One 64-lane wave per sequence: lane 0 runs the transition, the wave clears the 729-entry rejected-token bitmap.
-#include "decode_loop.cuh"
+#include "decode_loop.h"
 #include "commu_hip.h"
 
 namespace {

@@ -9,9 +9,9 @@
 // 16x16x32 blocks, K step 32, register-staged double-buffered LDS (one barrier per K step).
 // The MFMA is issued "swapped" (weight rows as the A operand) so that each lane ends up with
 // 4 consecutive output columns of one row: 8-byte bf16x4 / 16-byte f32x4 stores.
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
-#include "gemm8.cuh"
+#include "gemm8.h"
 #include <math.h>
 #include <stdlib.h>
 

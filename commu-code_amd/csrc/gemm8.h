@@ -1,6 +1,6 @@
 // Internal interface between gemm.hip (dispatch) and gemm8.hip (the 256 x 256 x 64 eight-phase kernels).
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 struct G8Args {
     const bf16* A;

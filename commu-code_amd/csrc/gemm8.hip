@@ -19,7 +19,7 @@
 //    index XOR (row >> 1) & 7: every ds_read_b128 lane group touches 16 distinct 16-byte slots (conflict-free).
 //  * The load stream runs continuously across output tiles: the next tile's first K-tiles are in flight while the
 //    finished tile is written out.
-#include "gemm8.cuh"
+#include "gemm8.h"
 #include "commu_hip.h"
 #include <stdlib.h>
 

@@ -15,7 +15,7 @@
 // emulation in tests/test_fp8_gemm_gpu.py with asymmetric operands): lane l holds row l & 15 of its operand; with
 // g = l >> 4 its first four dwords are k = 16 g .. 16 g + 15 and its last four k = 64 + 16 g .. 64 + 16 g + 15, while the
 // scale operand of lane group g (byte 0, op_sel 0) is the row's scale of the 32-block k = 32 g .. 32 g + 31.
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
 
 namespace {

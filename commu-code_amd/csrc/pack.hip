@@ -11,23 +11,27 @@ extern "C" long long commu_pack_batch(const int64_t* tokens, const int64_t* offs
                                       const int64_t* pos, const int64_t* cnt, int B, int T, int64_t pad, int64_t* data,
                                       int64_t* target) {
     long long total = 0;
-    // row-major [T][B] outputs: walk rows outermost so that both output streams are written sequentially
-    const int64_t* base[1024];
-    int64_t n[1024];
-    if (B > 1024 || B <= 0 || T <= 0) return -22;
-    for (int c = 0; c < B; ++c) {
-        const bool live = seq[c] >= 0 && cnt[c] > 0;
-        base[c] = live ? tokens + offsets[seq[c]] + pos[c] : nullptr;
-        n[c] = live ? cnt[c] : 0;
-        total += n[c];
-    }
-    for (int r = 0; r < T; ++r) {
-        int64_t* d = data + (int64_t)r * B;
-        int64_t* t = target + (int64_t)r * B;
-        for (int c = 0; c < B; ++c) {
-            const bool in = r < n[c];
-            d[c] = in ? base[c][r] : pad;
-            t[c] = in ? base[c][r + 1] : pad;
+    if (B <= 0 || T <= 0) return -22;
+    // row-major [T][B] outputs: walk rows outermost so that both output streams are written sequentially; columns in
+    // blocks of 1024 (the per-column cursors live on the stack)
+    for (int c0 = 0; c0 < B; c0 += 1024) {
+        const int nb = B - c0 < 1024 ? B - c0 : 1024;
+        const int64_t* base[1024];
+        int64_t n[1024];
+        for (int c = 0; c < nb; ++c) {
+            const bool live = seq[c0 + c] >= 0 && cnt[c0 + c] > 0;
+            base[c] = live ? tokens + offsets[seq[c0 + c]] + pos[c0 + c] : nullptr;
+            n[c] = live ? cnt[c0 + c] : 0;
+            total += n[c];
+        }
+        for (int r = 0; r < T; ++r) {
+            int64_t* d = data + (int64_t)r * B + c0;
+            int64_t* t = target + (int64_t)r * B + c0;
+            for (int c = 0; c < nb; ++c) {
+                const bool in = r < n[c];
+                d[c] = in ? base[c][r] : pad;
+                t[c] = in ? base[c][r + 1] : pad;
+            }
         }
     }
     return total;

@@ -2,7 +2,7 @@
 // relattn3.hip: 32x32 MFMA / transposed-score layout).  Device helpers live in an anonymous namespace: every
 // translation unit gets its own copy.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 #include "commu_hip.h"
 
 struct AttnArgs {

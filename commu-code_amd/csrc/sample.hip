@@ -6,7 +6,7 @@
 //   infer_token   : draw one token from the result -- here by inverse CDF with an injected
 //                   uniform variate u[b] (torch.multinomial's stream is not reproducible).
 // A sequence whose kept mass is 0 (Q12: greedy argmax is a rejected token) gets token -1.
-#include "decode_loop.cuh"
+#include "decode_loop.h"
 #include "commu_hip.h"
 
 namespace {

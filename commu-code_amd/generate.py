@@ -78,7 +78,21 @@ def main(model_args, input_args, training_cfg=None, device_indices=None):
                                                     training_cfg, q)) for r, share in enumerate(shares)]
         for p_ in procs:
             p_.start()
-        results = dict(q.get() for _ in procs)
+        # a replica that dies natively (GPU fault, OOM kill) never reports: poll the queue and the processes
+        import queue as _queue
+        results = {}
+        while len(results) < len(procs):
+            try:
+                k_, v_ = q.get(timeout=1.0)
+                results[k_] = v_
+            except _queue.Empty:
+                dead = [(r, p_.exitcode) for r, p_ in enumerate(procs)
+                        if r not in results and not p_.is_alive() and p_.exitcode not in (None, 0)]
+                if dead:
+                    for p_ in procs:
+                        if p_.is_alive():
+                            p_.terminate()
+                    raise RuntimeError(f"generation replica {dead[0][0]} died with exit code {dead[0][1]}")
         for p_ in procs:
             p_.join()
         bad = [v for v in results.values() if isinstance(v, str)]

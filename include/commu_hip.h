@@ -132,7 +132,7 @@ int commu_reduce_slabs_f32(float* dst, const float* src, size_t n, int nslabs, s
 /* ---- embedding (AdaptiveEmbedding.forward, model.py:409-420) and its gradient */
 /* (drop_p > 0: dropout of the scaled embedding, `core_out = self.drop(word_emb)`, model.py:585;
  *  every dropout in this ABI is the counter-based mask keep(seed, element index): a 32-bit integer hash of the
- *  index, KEYED by the seed between its two multiply rounds -- see common.cuh drop_keep and DESIGN.md) */
+ *  index, KEYED by the seed between its two multiply rounds -- see common.h drop_keep and DESIGN.md) */
 /* (a token id outside [0, V) -- the reference raises IndexError -- yields a NaN row, hence a NaN loss; likewise
  *  commu_ce_fwd returns NaN for a target outside [0, V): no out-of-bounds access, no silent garbage) */
 int commu_embed_fwd(const int64_t* tok, const float* E, void* out_bf16, int ldo, int ntok, int D, int V,

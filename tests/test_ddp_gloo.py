@@ -63,6 +63,8 @@ def _worker(rank, world, port, q):
         expect2 = torch.arange(n2, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
         ok = ok and torch.allclose(g2, expect2, rtol=1e-6)
         ok = ok and fired_early == [(31_000, 49_000), (13_000, 31_000)]      # two merged buckets before finish
+        # collective yes/no (graph capture: one rank's failure takes every rank to the eager step)
+        ok = ok and red.all_ok(True) and not red.all_ok(rank != 1) and not red.all_ok(False)
         cover = sorted(red2._fired)
         ok = ok and cover[0][0] == 0 and cover[-1][1] == n2 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
         q.put((rank, ok))
