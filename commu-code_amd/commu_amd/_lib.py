@@ -94,6 +94,7 @@ PROTOTYPES = {
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_q": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_kv": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
+    "commu_token_order": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "commu_attn_bwd_qrows": [c_i],
     "commu_attn_fwd_generation": [c_i],
     "commu_attn_band_slabs": [c_i, c_i],

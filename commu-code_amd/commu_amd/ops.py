@@ -360,8 +360,17 @@ def embed_fwd(tok, E, out=None, drop_p=0.0, drop_seed=0, ld=None):
 
 
 def token_order(tok, V):
-    """(perm, offs) for embed_bwd: stable argsort of the ids and the first sorted position of every id (int64 [V+1])."""
+    """(perm, offs) for embed_bwd: stable argsort of the ids and the first sorted position of every id (int64 [V+1]).
+    V <= 1024: the library's counting sort (three small launches, no framework kernels); ids outside [0, V) are left out
+    of the order (they contribute nothing either way).  Larger vocabularies: torch.sort + searchsorted."""
     flat = tok.reshape(-1)
+    if V <= 1024 and flat.is_cuda and flat.dtype == torch.int64 and flat.is_contiguous():
+        n = flat.numel()
+        perm = torch.empty(n, device=flat.device, dtype=torch.int64)
+        offs = torch.empty(V + 1, device=flat.device, dtype=torch.int64)
+        ws = torch.empty(64 * V, device=flat.device, dtype=torch.int32)
+        call("commu_token_order", _p(flat), n, V, _p(perm), _p(offs), _p(ws), _s())
+        return perm, offs
     vals, perm = torch.sort(flat, stable=True)
     offs = torch.searchsorted(vals, torch.arange(V + 1, device=tok.device, dtype=vals.dtype))
     return perm, offs

@@ -489,12 +489,12 @@ __global__ __launch_bounds__(256) void colsum_slab_kernel(const T* __restrict__ 
     for (int e = 0; e < V; ++e) a[e] = 0.f;
     if (c0 < cols) {          // (cols rounded up to V by the caller: whole 16-byte chunks inside the row pitch)
         int r = rbeg + w;
-        for (; r + 12 < rend; r += 16) {          // four rows in flight per wave
-            f32x4 v[4];
+        for (; r + 28 < rend; r += 32) {          // eight rows in flight per wave
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(X + (size_t)(r + 4 * u) * ldx + c0);
+            for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(X + (size_t)(r + 4 * u) * ldx + c0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 if constexpr (V == 8) {
                     const bf16x8 b = __builtin_bit_cast(bf16x8, v[u]);
 #pragma unroll
@@ -526,33 +526,35 @@ __global__ __launch_bounds__(256) void colsum_slab_kernel(const T* __restrict__ 
     }
 }
 
-// out[c] += sum_{r < rows} X[r * ldx + c] for fp32 X, rows in order; up to three planes (blockIdx.y: X + z * plane,
-// out = o0 / o1 / o2, a null output is skipped).  One workgroup per 64 columns: 16 row lanes x 16 float4 column lanes.
+// out[c] += sum_{r < rows} X[r * ldx + c] for fp32 X, fixed order; up to three planes (blockIdx.y: X + z * plane,
+// out = o0 / o1 / o2, a null output is skipped).  One workgroup per SIXTEEN columns: 64 row lanes x 4 float4 column lanes
+// (with 64 columns per workgroup a 512-column sum ran on 8 workgroups that each walked up to 1024 partial rows 16 at a
+// time: 53 us of dependent round trips on a 256-CU chip; 32-96 workgroups and a quarter of the trips: a few us).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ X, int ldx, size_t plane, int rows,
                                                            int cols, float* __restrict__ o0, float* __restrict__ o1,
                                                            float* __restrict__ o2, float alpha) {
-    __shared__ f32x4 red[16][16];
+    __shared__ f32x4 red[64][4];
     const int z = blockIdx.y;
     float* out = z == 0 ? o0 : (z == 1 ? o1 : o2);
     if (out == nullptr) return;
     const float* P = X + (size_t)z * plane;
-    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
-    const int c0 = blockIdx.x * 64 + cl * 4;
+    const int rl = threadIdx.x >> 2, cl = threadIdx.x & 3;
+    const int c0 = blockIdx.x * 16 + cl * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (c0 < cols) {
         const bool vec = c0 + 3 < cols && ((ldx & 3) == 0) && ((((size_t)P) & 15) == 0);
         int r = rl;
         if (vec) {
-            for (; r + 48 < rows; r += 64) {          // four loads in flight
+            for (; r + 192 < rows; r += 256) {          // four loads in flight
                 f32x4 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(P + (size_t)(r + 16 * u) * ldx + c0);
+                for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(P + (size_t)(r + 64 * u) * ldx + c0);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) a += v[u];
             }
-            for (; r < rows; r += 16) a += *(const f32x4*)(P + (size_t)r * ldx + c0);
+            for (; r < rows; r += 64) a += *(const f32x4*)(P + (size_t)r * ldx + c0);
         } else {
-            for (; r < rows; r += 16)
+            for (; r < rows; r += 64)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (c0 + e < cols) a[e] += P[(size_t)r * ldx + c0 + e];
@@ -560,12 +562,17 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
     red[rl][cl] = a;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = blockIdx.x * 64 + threadIdx.x;
+#pragma unroll
+    for (int st = 32; st >= 4; st >>= 1) {          // fixed tree over the row lanes
+        if (rl < st) red[rl][cl] += red[rl + st][cl];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) {
+        const int c = blockIdx.x * 16 + threadIdx.x;
         if (c < cols) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += red[k][threadIdx.x >> 2][threadIdx.x & 3];
+            for (int k = 0; k < 4; ++k) s += red[k][threadIdx.x >> 2][threadIdx.x & 3];
             out[c] += alpha * s;
         }
     }
@@ -911,6 +918,77 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
     return 0;
 }
 
+// Token order for commu_embed_bwd_sorted without a library sort: a stable counting sort over the V <= 1024 ids.
+//   1. per-workgroup histograms of the ids (LDS, integer atomics) -> hist[g][V]
+//   2. offs[v] = exclusive prefix of the id totals (one workgroup)
+//   3. one WAVE per id scans the token list (64 K tokens = 512 KB: it stays in L2) and writes the positions of its id in
+//      increasing order behind offs[v] -- ballots give every match its rank inside a step, so the order is the token order
+//      (= a stable argsort) whatever the schedule.
+// ids outside [0, V) are left out (offs[V] = number of valid tokens; the tail of perm is zero-filled: readable row 0).
+constexpr int TOK_HIST_WG = 64;
+__global__ __launch_bounds__(256) void tok_hist_kernel(const int64_t* __restrict__ tok, int ntok, int V, int* __restrict__ hist) {
+    __shared__ int h[1024];
+    for (int v = threadIdx.x; v < V; v += 256) h[v] = 0;
+    __syncthreads();
+    const int per = (ntok + TOK_HIST_WG - 1) / TOK_HIST_WG;
+    const int lo = blockIdx.x * per, hi = min(ntok, lo + per);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const int64_t t = tok[i];
+        if (t >= 0 && t < V) atomicAdd(&h[(int)t], 1);
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < V; v += 256) hist[blockIdx.x * V + v] = h[v];
+}
+__global__ __launch_bounds__(1024) void tok_scan_kernel(const int* __restrict__ hist, int V, int64_t* __restrict__ offs) {
+    __shared__ int tot[1024];
+    const int v = threadIdx.x;
+    int s = 0;
+    if (v < V)
+        for (int g = 0; g < TOK_HIST_WG; ++g) s += hist[g * V + v];
+    tot[v] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive scan
+        const int add = v >= d ? tot[v - d] : 0;
+        __syncthreads();
+        tot[v] += add;
+        __syncthreads();
+    }
+    if (v < V) offs[v + 1] = tot[v];
+    if (v == 0) offs[0] = 0;
+}
+__global__ __launch_bounds__(256) void tok_scatter_kernel(const int64_t* __restrict__ tok, int ntok, int V,
+                                                          const int64_t* __restrict__ offs, int64_t* __restrict__ perm) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v == V) {                                 // the wave after the last id: zero the tail (tokens left out)
+        for (long long k = offs[V] + lane; k < ntok; k += 64) perm[k] = 0;
+        return;
+    }
+    if (v > V) return;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    long long at = offs[v];
+    for (int p0 = 0; p0 < ntok; p0 += 128) {
+        const int i0 = p0 + 2 * lane;
+        const int64_t t0 = i0 < ntok ? tok[i0] : -1, t1 = i0 + 1 < ntok ? tok[i0 + 1] : -1;
+        const bool m0 = t0 == v, m1 = t1 == v;
+        const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+        const int before = __popcll(b0 & lt) + __popcll(b1 & lt);
+        if (m0) perm[at + before] = i0;
+        if (m1) perm[at + before + (m0 ? 1 : 0)] = i0 + 1;
+        at += __popcll(b0) + __popcll(b1);
+    }
+}
+
+extern "C" int commu_token_order(const int64_t* tok, int ntok, int V, int64_t* perm, int64_t* offs, int* ws,
+                                 hipStream_t stream) {
+    if (ntok <= 0 || V <= 0 || V > 1024) return -22;
+    COMMU_LAUNCH(tok_hist_kernel, dim3(TOK_HIST_WG), dim3(256), 0, stream, tok, ntok, V, ws);
+    COMMU_LAUNCH(tok_scan_kernel, dim3(1), dim3(1024), 0, stream, ws, V, offs);
+    COMMU_LAUNCH(tok_scatter_kernel, dim3((V + 1 + 3) / 4), dim3(256), 0, stream, tok, ntok, V, offs, perm);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
 /* rows (of D floats) of the workspace commu_embed_bwd_sorted needs for ntok tokens and V ids */
 extern "C" int commu_embed_bwd_ws_rows(int ntok, int V) { return V + (ntok + EMB_CHUNK - 1) / EMB_CHUNK + 1; }
 
@@ -991,7 +1069,8 @@ extern "C" int commu_colsum_slabs(int rows, int cols, int elem_bytes) {
     const int strip = elem_bytes == 2 ? 512 : 256;
     const int nx = (cols + strip - 1) / strip;
     const int ny = (rows + 63) / 64;
-    const int cap = small ? 256 : (1024 + nx - 1) / nx;          // ~1024 workgroups on a large input
+    const int cap = small ? 256 : (512 + nx - 1) / nx;           // ~512 workgroups on a large input: two per CU, and the
+                                                                 // final pass walks at most 512 partial rows
     return ny > cap ? cap : ny;
 }
 
@@ -1002,7 +1081,7 @@ static int colsum_launch(const T* X, int ldx, int rows, int cols, float* out, fl
     constexpr int V = sizeof(T) == 2 ? 8 : 4;
     const int ny = commu_colsum_slabs(rows, cols, (int)sizeof(T));
     if (ny == 0) {          // small fp32 input
-        COMMU_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, (const float*)X, ldx, (size_t)0,
+        COMMU_LAUNCH(colsum_final_kernel, dim3((cols + 15) / 16, 1), dim3(256), 0, stream, (const float*)X, ldx, (size_t)0,
                      rows, cols, out, (float*)nullptr, (float*)nullptr, alpha);
         COMMU_LAUNCH_CHECK();
         return 0;
@@ -1011,7 +1090,7 @@ static int colsum_launch(const T* X, int ldx, int rows, int cols, float* out, fl
     if (ws == nullptr || ws_rows < ny || colsv > ldx || (ldx % V) || (((size_t)X) & 15)) return -22;
     COMMU_LAUNCH((colsum_slab_kernel<T>), dim3((colsv + 64 * V - 1) / (64 * V), ny), dim3(256), 0, stream, X, ldx, rows,
                  colsv, ws, (rows + ny - 1) / ny);
-    COMMU_LAUNCH(colsum_final_kernel, dim3((cols + 63) / 64, 1), dim3(256), 0, stream, ws, colsv, (size_t)0, ny, cols, out,
+    COMMU_LAUNCH(colsum_final_kernel, dim3((cols + 15) / 16, 1), dim3(256), 0, stream, ws, colsv, (size_t)0, ny, cols, out,
                  (float*)nullptr, (float*)nullptr, alpha);
     COMMU_LAUNCH_CHECK();
     return 0;
@@ -1026,7 +1105,7 @@ extern "C" int commu_layernorm_bwd_reduce(const float* part, int nblk, int D, fl
                                           float* dbias, hipStream_t stream) {
     if (nblk <= 0 || D <= 0) return 0;
     // part is [nblk][3][D]: plane z of row r at part + (3 r + z) D  ->  row pitch 3 D, plane offset D
-    COMMU_LAUNCH(colsum_final_kernel, dim3((D + 63) / 64, 3), dim3(256), 0, stream, part, 3 * D, (size_t)D, nblk, D,
+    COMMU_LAUNCH(colsum_final_kernel, dim3((D + 15) / 16, 3), dim3(256), 0, stream, part, 3 * D, (size_t)D, nblk, D,
                  dgamma, dbeta, dbias, 1.f);
     COMMU_LAUNCH_CHECK();
     return 0;

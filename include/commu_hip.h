@@ -146,6 +146,10 @@ int commu_embed_bwd(const int64_t* tok, const void* dX_bf16, int ldx, float* dE,
  * wave does not depend on how often an id occurs (the pad / start id is a quarter of a real batch); fixed summation order,
  * no atomics. */
 int commu_embed_bwd_ws_rows(int ntok, int V);
+/* (perm, offs) of the line above from the token ids themselves: a stable counting sort (V <= 1024; -22 otherwise: sort
+ * with the framework).  ws: 64 * V ints of scratch.  ids outside [0, V) are left out: offs[V] = number of valid tokens,
+ * perm[offs[V] ..) = 0. */
+int commu_token_order(const int64_t* tok, int ntok, int V, int64_t* perm, int64_t* offs, int* ws, hipStream_t stream);
 int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* ws, int ntok, int D,
                            int V, float* dE, float scale, int accumulate, unsigned drop_seed, float drop_p,
                            hipStream_t stream);

@@ -89,6 +89,33 @@ def test_config_shape_loss_and_grads_vs_oracle(case):
     assert not bad, (tag, bad)
 
 
+def test_bench_shape_full_batch_columns_vs_oracle():
+    """The headline shape AT THE BENCH BATCH (64 columns x 1024 tokens, eval mode): the paths that depend on the grid
+    size -- grouped / eight-phase GEMMs over 65 536 rows, the fused band pass, the XCD tile order, the 256-row attention
+    workgroups over 512 (batch, head) pairs -- against the oracle on three of the 64 columns (columns are independent in
+    the forward pass: the oracle runs them alone), and the same three columns against a 3-column run of the build."""
+    L, H, D, DI, T, B = 6, 8, 512, 1024, 1024, 64
+    model, cfg, s, params = build(L, H, D, DI, T, 0, seed=21)
+    model.eval()
+    g = torch.Generator().manual_seed(17)
+    data = torch.randint(1, 729, (T, B), generator=g)
+    target = torch.randint(1, 729, (T, B), generator=g)
+    target[-9:, 5] = 0                                           # some pads in a checked column
+    reset = torch.zeros(B, dtype=torch.bool)
+    cols = [0, 5, 63]
+    with torch.no_grad():
+        loss, _ = model(data.to(DEV), target.to(DEV), reset.to(DEV), None)
+        loss = loss.float().cpu()
+        nll, _ = X.forward_loss(params, s, data[:, cols], target[:, cols], reset[cols], None, 0, False)
+        small, _ = model(data[:, cols].contiguous().to(DEV), target[:, cols].contiguous().to(DEV),
+                         reset[cols].to(DEV), None)
+    err = (loss[:, cols] - nll).abs()
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 8e-3, (float(err.max()), float(err.mean()))
+    assert bool(torch.isfinite(loss).all())
+    d = (loss[:, cols] - small.float().cpu()).abs()               # same kernels, other grids: bf16 rounding only
+    assert float(d.max()) < 3e-2 and float(d.mean()) < 3e-3, (float(d.max()), float(d.mean()))
+
+
 def test_bench_shape_full_batch_trains():
     """configs[1] at the bench batch (64 x 1024 tokens): finite loss that goes down over optimiser steps."""
     from commu_amd.model.config_helper import get_cfg

@@ -335,6 +335,29 @@ def test_embed_bwd_token_order(D, ld):
     assert relerr(scan, dE.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("n", [1, 130, 9000, 65536])
+def test_token_order_counting_sort_is_the_stable_argsort(n):
+    """commu_token_order (histogram -> scan -> one wave per id) == torch.sort(stable=True) + searchsorted on the valid ids,
+    with a dominating id, empty ids and ids outside the vocabulary (left out; the tail of perm reads row 0)."""
+    o = ops()
+    V = 729
+    tok = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(n))
+    if n >= 130:
+        tok[n // 4: n // 2] = 0
+        tok[5:9] = V + 3
+        tok[9:12] = -7
+        tok[tok == 11] = 12          # an id that never occurs
+    perm, offs = o.token_order(tok.to(DEV), V)
+    perm, offs = perm.cpu(), offs.cpu()
+    valid = ((tok >= 0) & (tok < V)).nonzero().flatten()
+    vals, order = torch.sort(tok[valid], stable=True)
+    ref_perm = valid[order]
+    ref_offs = torch.searchsorted(vals, torch.arange(V + 1))
+    assert torch.equal(offs, ref_offs)
+    assert torch.equal(perm[: valid.numel()], ref_perm)
+    assert bool((perm[valid.numel():] == 0).all())
+
+
 def test_out_of_range_ids_poison_the_loss():
     """A token / target id outside [0, V) (the reference raises IndexError) must neither read out of bounds nor
     pass silently: the embedding row and the row's nll come out NaN, the other rows are untouched."""

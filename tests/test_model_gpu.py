@@ -83,12 +83,14 @@ def test_g1_forward_backward_vs_reference(golden_dir, tag):
     _dump(f"g1_{tag}", {"relerr": worst, "cos": cosines})
     # every gradient tensor points the same way as the reference's ...
     assert min(cosines.values()) > 0.995, cosines
-    # ... and matches element-wise to bf16 accuracy (chain through 2 layers).  The first FFN Linear is
-    # the exception: a pre-activation within bf16 rounding of 0 flips its ReLU gate, which changes one
-    # whole term of that unit's weight/bias gradient (36 tokens here) -- a property of ReLU, not an error.
+    # ... and matches element-wise to bf16 accuracy (chain through 2 layers).  The first FFN Linear is not held to
+    # an element-wise bound HERE: a pre-activation within bf16 rounding of 0 flips its ReLU gate against the fp32
+    # reference, which changes one whole term of that unit's weight / bias gradient (36 tokens here) -- a property of
+    # ReLU.  Its element-wise check is test_g1_gradients_with_the_builds_relu_gates_injected (6e-2, the build's own
+    # gates given to the oracle); the cosine bound above covers it here.
     for k, v in worst.items():
-        tol = 0.35 if "pos_ff.CoreNet.0" in k else 6e-2
-        assert v < tol, (k, v)
+        if "pos_ff.CoreNet.0" not in k:
+            assert v < 6e-2, (k, v)
 
 
 def test_g1_masked_mean_matches_indexing(golden_dir):
