@@ -919,18 +919,19 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
 }
 
 // Token order for commu_embed_bwd_sorted without a library sort: a stable counting sort over the V <= 1024 ids.
-//   1. per-workgroup histograms of the ids (LDS, integer atomics) -> hist[g][V]
-//   2. offs[v] = exclusive prefix of the id totals (one workgroup)
-//   3. one WAVE per id scans the token list (64 K tokens = 512 KB: it stays in L2) and writes the positions of its id in
-//      increasing order behind offs[v] -- ballots give every match its rank inside a step, so the order is the token order
-//      (= a stable argsort) whatever the schedule.
+//   1. histogram of the ids of each of 64 consecutive chunks of the token list (LDS, integer atomics) -> hist[g][V]
+//   2. offs[v] = exclusive prefix of the id totals; hist[g][v] becomes the first sorted position of id v in chunk g
+//   3. one wave per chunk walks its tokens 64 at a time IN ORDER: the lanes holding the same id find each other with ten
+//      ballots (one per id bit), a lane's position is base[g][id] + tokens of that id seen in earlier steps (an LDS
+//      counter) + equal-id lanes below it -- a stable argsort whatever the schedule.  (One wave per ID scanning the whole
+//      list, the first form, took 307 us: 512 dependent steps per wave; this form 29 us.)
 // ids outside [0, V) are left out (offs[V] = number of valid tokens; the tail of perm is zero-filled: readable row 0).
-constexpr int TOK_HIST_WG = 64;
+constexpr int TOK_CHUNKS = 64;
 __global__ __launch_bounds__(256) void tok_hist_kernel(const int64_t* __restrict__ tok, int ntok, int V, int* __restrict__ hist) {
     __shared__ int h[1024];
     for (int v = threadIdx.x; v < V; v += 256) h[v] = 0;
     __syncthreads();
-    const int per = (ntok + TOK_HIST_WG - 1) / TOK_HIST_WG;
+    const int per = (ntok + TOK_CHUNKS - 1) / TOK_CHUNKS;
     const int lo = blockIdx.x * per, hi = min(ntok, lo + per);
     for (int i = lo + threadIdx.x; i < hi; i += 256) {
         const int64_t t = tok[i];
@@ -939,12 +940,13 @@ __global__ __launch_bounds__(256) void tok_hist_kernel(const int64_t* __restrict
     __syncthreads();
     for (int v = threadIdx.x; v < V; v += 256) hist[blockIdx.x * V + v] = h[v];
 }
-__global__ __launch_bounds__(1024) void tok_scan_kernel(const int* __restrict__ hist, int V, int64_t* __restrict__ offs) {
+__global__ __launch_bounds__(1024) void tok_scan_kernel(int* __restrict__ hist, int V, int ntok, int64_t* __restrict__ offs,
+                                                        int64_t* __restrict__ perm) {
     __shared__ int tot[1024];
     const int v = threadIdx.x;
     int s = 0;
     if (v < V)
-        for (int g = 0; g < TOK_HIST_WG; ++g) s += hist[g * V + v];
+        for (int g = 0; g < TOK_CHUNKS; ++g) s += hist[g * V + v];
     tot[v] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {          // inclusive scan
@@ -953,38 +955,54 @@ __global__ __launch_bounds__(1024) void tok_scan_kernel(const int* __restrict__ 
         tot[v] += add;
         __syncthreads();
     }
-    if (v < V) offs[v + 1] = tot[v];
-    if (v == 0) offs[0] = 0;
-}
-__global__ __launch_bounds__(256) void tok_scatter_kernel(const int64_t* __restrict__ tok, int ntok, int V,
-                                                          const int64_t* __restrict__ offs, int64_t* __restrict__ perm) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v == V) {                                 // the wave after the last id: zero the tail (tokens left out)
-        for (long long k = offs[V] + lane; k < ntok; k += 64) perm[k] = 0;
-        return;
+    if (v < V) {
+        offs[v + 1] = tot[v];
+        int run = tot[v] - s;                      // first sorted position of id v
+        for (int g = 0; g < TOK_CHUNKS; ++g) {
+            const int c = hist[g * V + v];
+            hist[g * V + v] = run;
+            run += c;
+        }
     }
-    if (v > V) return;
+    if (v == 0) offs[0] = 0;
+    for (int k = tot[V - 1] + v; k < ntok; k += 1024) perm[k] = 0;          // tokens left out
+}
+__global__ __launch_bounds__(64) void tok_scatter_kernel(const int64_t* __restrict__ tok, int ntok, int V,
+                                                         const int* __restrict__ base, int64_t* __restrict__ perm) {
+    __shared__ int seen[1024];
+    const int lane = threadIdx.x, g = blockIdx.x;
+    for (int v = lane; v < V; v += 64) seen[v] = 0;
+    __syncthreads();
+    const int per = (ntok + TOK_CHUNKS - 1) / TOK_CHUNKS;
+    const int lo = g * per, hi = min(ntok, lo + per);
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    long long at = offs[v];
-    for (int p0 = 0; p0 < ntok; p0 += 128) {
-        const int i0 = p0 + 2 * lane;
-        const int64_t t0 = i0 < ntok ? tok[i0] : -1, t1 = i0 + 1 < ntok ? tok[i0 + 1] : -1;
-        const bool m0 = t0 == v, m1 = t1 == v;
-        const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
-        const int before = __popcll(b0 & lt) + __popcll(b1 & lt);
-        if (m0) perm[at + before] = i0;
-        if (m1) perm[at + before + (m0 ? 1 : 0)] = i0 + 1;
-        at += __popcll(b0) + __popcll(b1);
+    for (int p0 = lo; p0 < hi; p0 += 64) {
+        const int i = p0 + lane;
+        const int64_t t = i < hi ? tok[i] : -1;
+        const bool valid = t >= 0 && t < V;
+        const int id = valid ? (int)t : 0;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 10; ++b) {
+            const bool bit = (id >> b) & 1;
+            const unsigned long long bb = __ballot(valid && bit);
+            m &= bit ? bb : ~bb;
+        }
+        if (valid) {
+            const int before = seen[id];                          // (every lane of the group reads before its top lane writes)
+            perm[base[g * V + id] + before + __popcll(m & lt)] = i;
+            if ((m >> lane) == 1ull) seen[id] = before + __popcll(m);      // the group's top lane
+        }
+        __syncthreads();
     }
 }
 
 extern "C" int commu_token_order(const int64_t* tok, int ntok, int V, int64_t* perm, int64_t* offs, int* ws,
                                  hipStream_t stream) {
     if (ntok <= 0 || V <= 0 || V > 1024) return -22;
-    COMMU_LAUNCH(tok_hist_kernel, dim3(TOK_HIST_WG), dim3(256), 0, stream, tok, ntok, V, ws);
-    COMMU_LAUNCH(tok_scan_kernel, dim3(1), dim3(1024), 0, stream, ws, V, offs);
-    COMMU_LAUNCH(tok_scatter_kernel, dim3((V + 1 + 3) / 4), dim3(256), 0, stream, tok, ntok, V, offs, perm);
+    COMMU_LAUNCH(tok_hist_kernel, dim3(TOK_CHUNKS), dim3(256), 0, stream, tok, ntok, V, ws);
+    COMMU_LAUNCH(tok_scan_kernel, dim3(1), dim3(1024), 0, stream, ws, V, ntok, offs, perm);
+    COMMU_LAUNCH(tok_scatter_kernel, dim3(TOK_CHUNKS), dim3(64), 0, stream, tok, ntok, V, ws, perm);
     COMMU_LAUNCH_CHECK();
     return 0;
 }
