@@ -36,6 +36,14 @@ class ReduceItem(C.Structure):
                 ("cp", c_i)]
 
 
+class ColsumSource(C.Structure):
+    _fields_ = [("X", c_p), ("ldx", c_i), ("rows", c_i), ("alpha", C.c_float), ("pad_", c_i)]
+
+
+class ColsumTask(C.Structure):
+    _fields_ = [("out", c_p), ("cols", c_i), ("src_begin", c_i), ("src_end", c_i), ("pad_", c_i)]
+
+
 class TnProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("lda", c_i), ("ldb", c_i), ("N", c_i), ("K", c_i), ("out_off", C.c_longlong)]
 
@@ -94,6 +102,8 @@ PROTOTYPES = {
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_q": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_kv": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
+    "commu_colsum_group_f32": [c_p, c_i, c_p, c_i, c_p],
+    "commu_colsum_slab_pass": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "commu_token_order": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "commu_attn_bwd_qrows": [c_i],
     "commu_attn_fwd_generation": [c_i],
@@ -126,7 +136,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"commu_decode_tail_pack_bytes": C.c_longlong, "commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
             "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_attn_fwd_generation", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_attn_fwd_generation", "commu_colsum_slab_pass", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
             "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_decode_tail_pack_bytes", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
 
 _lib = None

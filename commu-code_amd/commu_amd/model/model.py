@@ -703,7 +703,11 @@ class MemTransformerLM(nn.Module):
         g = dloss.reshape(-1).to(F32)
         dlogits = ops.ce_bwd(sv.logits, sv.target, sv.ce_lse, g, V)             # [TB, 768] bf16, pad cols 0
         keep.append(dlogits)
-        defer_light(lambda: ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,))))
+        # every final column-sum pass of the step (bias, LayerNorm-parameter, r_w_bias / r_r_bias gradients) runs as ONE
+        # launch at the end of the pass; only the slab passes over the large bf16 operands are issued where they arise
+        # (not under an overlapped gradient exchange: a layer's slice must be final when its hook fires)
+        cgrp = ops.ColsumGroup() if getattr(self, "grad_ready_hook", None) is None else None
+        defer_light(lambda: ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)), group=cgrp))
         gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
         wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))
         p, patt = sv.p, sv.patt
@@ -760,7 +764,7 @@ class MemTransformerLM(nn.Module):
             keep.append(part)
             defer_light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
                 part, gv(pre + "pos_ff.layer_norm.weight", (Dt,)), gv(pre + "pos_ff.layer_norm.bias", (Dt,)),
-                gv(pre + "pos_ff.CoreNet.3.bias", (Dt,))))
+                gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)), group=cgrp))
             wgrad(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
             hb = sv.hbits[i]
             if hb is not None and ops.signbits_words(TB, DI, D, dz2m.stride(0), sh[f"w2_t{i}"].stride(0), DI) == hb.numel():
@@ -768,7 +772,8 @@ class MemTransformerLM(nn.Module):
             else:
                 dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
             wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
-            defer_light(lambda dhid=dhid, pre=pre: ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,))))
+            defer_light(lambda dhid=dhid, pre=pre: ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)),
+                                                             group=cgrp))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
@@ -777,7 +782,7 @@ class MemTransformerLM(nn.Module):
                 dz1m = dz1
             keep.append(part)
             defer_light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
-                part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)), gv(pre + "dec_attn.layer_norm.bias", (Dt,))))
+                part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)), gv(pre + "dec_attn.layer_norm.bias", (Dt,)), group=cgrp))
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             last = i == 0
             if last:
@@ -797,7 +802,8 @@ class MemTransformerLM(nn.Module):
                             vb_k, sv.reset, T, M, B, H, DH, sv.same_length, sv.mem_len, sv.vec[i], dvec,
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
-                            scratch=scr[i & 1], defer=(defer_last if last else defer) if side is not None else None)
+                            scratch=scr[i & 1], defer=(defer_last if last else defer) if side is not None else None,
+                            colsum_group=cgrp)
             gWr = gv(pre + "dec_attn.r_net.weight", (HDt, Dt))
             if side is None:
                 self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"))
@@ -840,6 +846,13 @@ class MemTransformerLM(nn.Module):
             for t_ in order_box["o"]:
                 t_.record_stream(main)          # (allocated on the second side stream, read here)
         ops.embed_bwd(sv.tokens, dy, gE, accumulate=True, drop_p=p, drop_seed=ss(0), order=order_box["o"])
+        if cgrp is not None:
+            if side is not None:      # the grouped final column sums: after every slab pass on either side stream
+                with torch.cuda.stream(side2):
+                    side2.wait_stream(side)
+                    cgrp.flush()
+            else:
+                cgrp.flush()
         join()
         if pad:
             gu_t.view(H, DHt).add_(gu.view(H, DH)[:, :DHt])

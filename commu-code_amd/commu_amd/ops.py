@@ -426,19 +426,80 @@ def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, 
     return dz, part[:nblk]
 
 
-def layernorm_bwd_reduce(part, dgamma, dbeta, dbias=None):
-    """One launch for the three partial-sum planes of layernorm_bwd: accumulates into the gradients."""
+class ColsumGroup:
+    """Collects the final column-sum passes of a backward step (bias, LayerNorm-parameter and shared attention-bias
+    gradients) and runs them as ONE launch (commu_colsum_group_f32): sources that add into the same output are walked by
+    the same workgroups, in the order they were added.  colsum(..., group=g) / layernorm_bwd_reduce(..., group=g) only run
+    their slab pass (if any) right away; flush() launches the rest on the current stream."""
+
+    def __init__(self):
+        self.by_out = {}          # out.data_ptr() -> [out, cols, [(X tensor, ptr, ldx, rows, alpha), ...]]
+        self.keep = []
+
+    def add(self, out, cols, X, ptr, ldx, rows, alpha):
+        ent = self.by_out.setdefault(out.data_ptr(), [out, cols, []])
+        assert ent[1] == cols
+        ent[2].append((ptr, ldx, rows, float(alpha)))
+        self.keep.append(X)
+
+    def flush(self):
+        tasks, srcs = [], []
+        cur = torch.cuda.current_stream()
+        for t_ in self.keep:
+            t_.record_stream(cur)          # (sources were allocated on the stream that produced them)
+
+        def launch():
+            if not tasks:
+                return
+            ta = (_lib.ColsumTask * len(tasks))()
+            sa = (_lib.ColsumSource * len(srcs))()
+            for i, (o, cols, b, e) in enumerate(tasks):
+                ta[i].out, ta[i].cols, ta[i].src_begin, ta[i].src_end = o, cols, b, e
+            for i, (ptr, ldx, rows, alpha) in enumerate(srcs):
+                sa[i].X, sa[i].ldx, sa[i].rows, sa[i].alpha = ptr, ldx, rows, alpha
+            call("commu_colsum_group_f32", ta, len(tasks), sa, len(srcs), _s())
+            tasks.clear()
+            srcs.clear()
+        for out, cols, lst in self.by_out.values():
+            if len(tasks) + 1 > 48 or len(srcs) + len(lst) > 64:
+                launch()
+            b = len(srcs)
+            srcs.extend(lst)
+            tasks.append((out.data_ptr(), cols, b, len(srcs)))
+        launch()
+        self.by_out, self.keep = {}, []
+
+
+def layernorm_bwd_reduce(part, dgamma, dbeta, dbias=None, group=None):
+    """One launch for the three partial-sum planes of layernorm_bwd: accumulates into the gradients (group: deferred
+    into the step's grouped final pass)."""
     nblk, _, D = part.shape
     assert part.is_contiguous() and part.dtype == F32
+    if group is not None:
+        for z, dst in enumerate((dgamma, dbeta, dbias)):
+            if dst is not None:
+                group.add(dst, D, part, part.data_ptr() + 4 * z * D, 3 * D, nblk, 1.0)
+        return
     call("commu_layernorm_bwd_reduce", _p(part), nblk, D, _p(dgamma), _p(dbeta), _p(dbias), _s())
 
 
-def colsum(X, out, alpha=1.0):
-    """out[c] += alpha * sum_r X[r, c]  (X bf16 or fp32; deterministic two-pass sum, no atomics)."""
+def colsum(X, out, alpha=1.0, group=None):
+    """out[c] += alpha * sum_r X[r, c]  (X bf16 or fp32; deterministic two-pass sum, no atomics).  group: only the slab
+    pass runs now, the final pass joins the group's single launch."""
     rows, cols = X.shape
     bf = X.dtype == BF16
     ny = call("commu_colsum_slabs", rows, cols, 2 if bf else 4)
-    ws = torch.empty(ny, round_up(cols, 8), device=X.device, dtype=F32) if ny > 0 else None
+    ws = torch.empty(ny, round_up(cols, 8 if bf else 4), device=X.device, dtype=F32) if ny > 0 else None
+    if group is not None:
+        if ny > 0:
+            got = call("commu_colsum_slab_pass", _p(X), 2 if bf else 4, X.stride(0), rows, cols, _p(ws), ny, _s())
+            if got != ny:
+                raise CommuHipError(f"commu_colsum_slab_pass returned {got} (expected {ny})")
+            group.add(out, cols, ws, ws.data_ptr(), ws.stride(0), ny, alpha)
+        else:
+            assert X.dtype == F32
+            group.add(out, cols, X, X.data_ptr(), X.stride(0), rows, alpha)
+        return out
     call("commu_colsum_bf16" if bf else "commu_colsum_f32", _p(X), X.stride(0), rows, cols, _p(out), _p(ws), ny,
          float(alpha), _s())
     return out
@@ -615,7 +676,7 @@ NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead 
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
-                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None, defer=None):
+                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None, defer=None, colsum_group=None):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
     drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
     dev = q.device
@@ -705,7 +766,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
             drd_reduce()
         else:
             defer(drd_reduce)
-        _bias_grads(dq, du_part, du, dvb, HD, dev, defer)
+        _bias_grads(dq, du_part, du, dvb, HD, dev, defer, colsum_group)
         return delta
     # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
     rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
@@ -728,19 +789,20 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         drd_part()
     else:
         defer(drd_part)
-    _bias_grads(dq, du_part, du, dvb, HD, dev, defer)
+    _bias_grads(dq, du_part, du, dvb, HD, dev, defer, colsum_group)
     return delta
 
 
-def _bias_grads(dq, du_part, du, dvb, HD, dev, defer):
+def _bias_grads(dq, du_part, du, dvb, HD, dev, defer, group=None):
     """d r_w_bias += colsum(dq_ac) ; d r_r_bias += colsum(dq) - colsum(dq_ac)   (gradients only: deferrable).
-    du_part holds the per-query-tile column sums of dq_ac; three column-sum launches, no temporaries."""
+    du_part holds the per-query-tile column sums of dq_ac; three column-sum launches, no temporaries (group: one slab pass
+    now, the three final passes in the step's grouped launch)."""
     def bias_part():
         if defer is not None:          # local scratch outlives the caller on the deferring stream
             du_part.record_stream(torch.cuda.current_stream())
-        colsum(du_part, du)
-        colsum(dq, dvb)
-        colsum(du_part, dvb, alpha=-1.0)
+        colsum(du_part, du, group=group)
+        colsum(dq, dvb, group=group)
+        colsum(du_part, dvb, alpha=-1.0, group=group)
     if defer is None:
         bias_part()
     else:

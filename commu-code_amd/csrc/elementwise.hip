@@ -1114,6 +1114,113 @@ static int colsum_launch(const T* X, int ldx, int rows, int cols, float* out, fl
     return 0;
 }
 
+// Every final pass of a backward step in ONE launch: a task is an output vector (a bias / LayerNorm-parameter / shared
+// attention-bias gradient) and the fp32 sources whose column sums it receives -- partial rows of a slab pass or of the
+// LayerNorm backward, per-tile sums of the attention kernels --, each with its factor.  Sources of one output are walked by
+// the same workgroup one after the other (fixed order, no two workgroups add into one address).  The 37 final passes of a
+// step were 37 launches of 8-96 workgroups on a side stream, each waiting ~30 us for free CUs.
+struct ColsumGroupArgs {
+    commu_colsum_source src[COMMU_COLSUM_MAX_SOURCES];
+    commu_colsum_task task[COMMU_COLSUM_MAX_TASKS];
+    int wg_begin[COMMU_COLSUM_MAX_TASKS + 1];
+    int ntask;
+};
+__global__ __launch_bounds__(256) void colsum_group_kernel(const ColsumGroupArgs a) {
+    __shared__ f32x4 red[64][4];
+    int t = 0;
+    while (t + 1 < a.ntask && (int)blockIdx.x >= a.wg_begin[t + 1]) ++t;
+    const commu_colsum_task tk = a.task[t];
+    const int rl = threadIdx.x >> 2, cl = threadIdx.x & 3;
+    const int c0 = ((int)blockIdx.x - a.wg_begin[t]) * 16 + cl * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int si = tk.src_begin; si < tk.src_end; ++si) {
+        const commu_colsum_source sc = a.src[si];
+        const float* P = sc.X;
+        const int ldx = sc.ldx, rows = sc.rows;
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+        if (c0 < tk.cols) {
+            const bool vec = c0 + 3 < tk.cols && ((ldx & 3) == 0) && ((((size_t)P) & 15) == 0);
+            int r = rl;
+            if (vec) {
+                for (; r + 192 < rows; r += 256) {          // four loads in flight
+                    f32x4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(P + (size_t)(r + 64 * u) * ldx + c0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) p += v[u];
+                }
+                for (; r < rows; r += 64) p += *(const f32x4*)(P + (size_t)r * ldx + c0);
+            } else {
+                for (; r < rows; r += 64)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < tk.cols) p[e] += P[(size_t)r * ldx + c0 + e];
+            }
+        }
+        acc += p * sc.alpha;
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int st = 32; st >= 4; st >>= 1) {
+        if (rl < st) red[rl][cl] += red[rl + st][cl];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) {
+        const int c = ((int)blockIdx.x - a.wg_begin[t]) * 16 + threadIdx.x;
+        if (c < tk.cols) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += red[k][threadIdx.x >> 2][threadIdx.x & 3];
+            tk.out[c] += s;
+        }
+    }
+}
+
+extern "C" int commu_colsum_group_f32(const commu_colsum_task* tasks, int ntask, const commu_colsum_source* srcs, int nsrc,
+                                      hipStream_t stream) {
+    if (ntask <= 0) return 0;
+    if (ntask > COMMU_COLSUM_MAX_TASKS || nsrc > COMMU_COLSUM_MAX_SOURCES || nsrc <= 0) return -22;
+    ColsumGroupArgs a = {};
+    int wg = 0;
+    for (int t = 0; t < ntask; ++t) {
+        if (tasks[t].src_begin < 0 || tasks[t].src_end > nsrc || tasks[t].src_begin > tasks[t].src_end ||
+            tasks[t].cols <= 0 || tasks[t].out == nullptr) return -22;
+        a.task[t] = tasks[t];
+        a.wg_begin[t] = wg;
+        wg += (tasks[t].cols + 15) / 16;
+    }
+    a.wg_begin[ntask] = wg;
+    a.ntask = ntask;
+    for (int i = 0; i < nsrc; ++i) a.src[i] = srcs[i];
+    COMMU_LAUNCH(colsum_group_kernel, dim3(wg), dim3(256), 0, stream, a);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
+/* the slab pass of commu_colsum_bf16 / _f32 alone: partial rows into ws (commu_colsum_slabs rows of `cols` rounded up to
+ * 8 / 4 floats); returns the number of partial rows written, 0 when the input needs no slab pass (sum it directly) */
+template <typename T>
+static int colsum_slabs_only(const T* X, int ldx, int rows, int cols, float* ws, int ws_rows, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    constexpr int V = sizeof(T) == 2 ? 8 : 4;
+    const int ny = commu_colsum_slabs(rows, cols, (int)sizeof(T));
+    if (ny == 0) return 0;
+    const int colsv = (cols + V - 1) / V * V;
+    if (ws == nullptr || ws_rows < ny || colsv > ldx || (ldx % V) || (((size_t)X) & 15)) return -22;
+    COMMU_LAUNCH((colsum_slab_kernel<T>), dim3((colsv + 64 * V - 1) / (64 * V), ny), dim3(256), 0, stream, X, ldx, rows,
+                 colsv, ws, (rows + ny - 1) / ny);
+    hipError_t e__ = hipGetLastError();
+    if (e__ != hipSuccess) return -(int)e__;
+    return ny;
+}
+extern "C" int commu_colsum_slab_pass(const void* X, int elem_bytes, int ldx, int rows, int cols, float* ws, int ws_rows,
+                                      hipStream_t stream) {
+    if (elem_bytes == 2) return colsum_slabs_only<bf16>((const bf16*)X, ldx, rows, cols, ws, ws_rows, stream);
+    if (elem_bytes == 4) return colsum_slabs_only<float>((const float*)X, ldx, rows, cols, ws, ws_rows, stream);
+    return -22;
+}
+
 extern "C" int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows,
                                  float alpha, hipStream_t stream) {
     return colsum_launch<bf16>((const bf16*)X, ldx, rows, cols, out, ws, ws_rows, alpha, stream);

@@ -182,6 +182,28 @@ int commu_colsum_bf16(const void* X, int ldx, int rows, int cols, float* out, fl
                       hipStream_t stream);
 int commu_colsum_f32(const float* X, int ldx, int rows, int cols, float* out, float* ws, int ws_rows, float alpha,
                      hipStream_t stream);
+/* The final passes of a whole backward step in one launch.  A task adds into out[0 .. cols) the column sums of its sources
+ * src[src_begin .. src_end) -- fp32 matrices of `rows` rows with row stride ldx (partial rows of commu_colsum_slab_pass or
+ * of commu_layernorm_bwd, per-tile sums of the attention kernels) -- each times its alpha, in the order given.  Two tasks
+ * must not share an output.  At most COMMU_COLSUM_MAX_TASKS tasks / COMMU_COLSUM_MAX_SOURCES sources per call. */
+#define COMMU_COLSUM_MAX_TASKS 48
+#define COMMU_COLSUM_MAX_SOURCES 64
+typedef struct commu_colsum_source {
+    const float* X;
+    int ldx, rows;
+    float alpha;
+    int pad_;
+} commu_colsum_source;
+typedef struct commu_colsum_task {
+    float* out;
+    int cols, src_begin, src_end, pad_;
+} commu_colsum_task;
+int commu_colsum_group_f32(const commu_colsum_task* tasks, int ntask, const commu_colsum_source* srcs, int nsrc,
+                           hipStream_t stream);
+/* the slab pass of commu_colsum_bf16 / _f32 on its own (elem_bytes 2 / 4): returns the number of partial rows written to
+ * ws (row stride = cols rounded up to 8 / 4), 0 when the input is small fp32 and is summed directly, < 0 on error */
+int commu_colsum_slab_pass(const void* X, int elem_bytes, int ldx, int rows, int cols, float* ws, int ws_rows,
+                           hipStream_t stream);
 
 /* ---- output layer loss (ProjectedAdaptiveLogSoftmax.forward, n_clusters == 0: model.py:64-73) */
 int commu_ce_fwd(const float* logits, int ldl, const int64_t* target, float* nll, float* lse, int rows,
