@@ -510,8 +510,8 @@ EXTRA_ROWS = [
      dict(d_model=500, heads=10, d_inner=1000, tgt_len=128, mem_len=1024, batch_per_gpu=256, batch_chunk=4)),
     ("cfg5_L12_D1024_H16_DI2048_T2048_M2048_b8_bf16",
      dict(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048, batch_per_gpu=8)),
-    ("cfg5_L12_D1024_H16_DI2048_T2048_M2048_b8_mxfp8_forward_gemms",
-     dict(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048, batch_per_gpu=8, fp8_forward=True)),
+    # (configs[4] names "fp8 MFMA GEMMs": the MX-fp8 forward path exists and is tested -- `--fp8-forward` -- but it is a
+    #  measured LOSS at every shape of this model (63.5 vs 60.6 ms at this row in round 3): it is not a bench row)
 ]
 
 

@@ -104,6 +104,8 @@ PROTOTYPES = {
     "commu_relattn_bwd_kv": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_colsum_group_f32": [c_p, c_i, c_p, c_i, c_p],
     "commu_colsum_slab_pass": [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "commu_gelu_fwd": [c_p, c_i, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
+    "commu_gelu_bwd": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
     "commu_token_order": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "commu_attn_bwd_qrows": [c_i],
     "commu_attn_fwd_generation": [c_i],

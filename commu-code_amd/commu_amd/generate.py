@@ -46,6 +46,8 @@ class DecodeState:
         if Lmax > self.MAX_POSITIONS:
             raise CommuHipError(f"decode cache of {Lmax} positions requested; this build supports {self.MAX_POSITIONS} "
                                 "(the reference's 1 + 4146 fits)")
+        if getattr(model, "ffn_activation", "relu") != "relu":
+            raise CommuHipError("the cached decode step is built for the reference's ReLU FFN only")
         fl = model._ensure_flat()
         dev = fl["dev"]
         self.model, self.B, self.Lmax = model, B, Lmax

@@ -72,10 +72,12 @@ class PositionalEmbedding(nn.Module):
 
 
 class PositionwiseFF(nn.Module):
-    def __init__(self, d_model, d_inner, dropout):
+    def __init__(self, d_model, d_inner, dropout, activation="relu"):
         super().__init__()
         self.d_model, self.d_inner, self.dropout = d_model, d_inner, dropout
-        self.CoreNet = nn.Sequential(nn.Linear(d_model, d_inner), nn.ReLU(inplace=True), nn.Dropout(dropout),
+        # (activation "gelu": a non-default option, MemTransformerLM.ffn_activation; same module slots / state_dict names)
+        act = nn.GELU() if activation == "gelu" else nn.ReLU(inplace=True)
+        self.CoreNet = nn.Sequential(nn.Linear(d_model, d_inner), act, nn.Dropout(dropout),
                                      nn.Linear(d_inner, d_model), nn.Dropout(dropout))   # model.py:163-169
         self.layer_norm = nn.LayerNorm(d_model)
 
@@ -116,7 +118,7 @@ def _low_priority_stream(dev):
 class _Saved:
     """Activations of one forward call kept for its backward."""
     __slots__ = ("T", "M", "B", "tokens", "target", "reset", "h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1",
-                 "rs1", "a", "hid", "hbits", "z2", "mu2", "rs2", "pd", "hL", "logits", "ce_lse", "same_length", "mem_len",
+                 "rs1", "a", "hid", "hbits", "zff", "z2", "mu2", "rs2", "pd", "hL", "logits", "ce_lse", "same_length", "mem_len",
                  "p", "patt", "seed")
 
 
@@ -486,7 +488,7 @@ class MemTransformerLM(nn.Module):
             sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
             sv.same_length, sv.mem_len = bool(self.same_length), int(self.mem_len)
             sv.p, sv.patt, sv.seed = p, patt, seed
-            for k in ("h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1", "rs1", "a", "hid", "hbits", "z2", "mu2", "rs2"):
+            for k in ("h", "cat", "qkv", "rd", "vec", "lse", "qs", "z1", "mu1", "rs1", "a", "hid", "hbits", "zff", "z2", "mu2", "rs2"):
                 setattr(sv, k, [])
         u, vb = self._uv()
         h_out = None
@@ -499,6 +501,11 @@ class MemTransformerLM(nn.Module):
             if o0 % 8 == 0 and (o1 - o0) % 8 == 0 and Dt % 8 == 0:
                 rd_all = ops.gemm_nt_layers(pd, self._flat["bf16"][o0:], HD, Dt, o1 - o0, L)
         fp8 = bool(getattr(self, "fp8_forward", False))
+        # FFN activation: "relu" (the reference, model.py:163-169: default and parity mode) or "gelu" (BASELINE.json's north
+        # star names a GELU-FFN; model.ffn_activation = "gelu": training / evaluation passes only, bf16 path)
+        gelu = getattr(self, "ffn_activation", "relu") == "gelu"
+        if gelu and fp8:
+            raise CommuHipError("ffn_activation 'gelu' is not available on the MX-fp8 forward path")
         if fp8 and (self._padded or D % 128 or DI % 128 or HD % 128):
             raise CommuHipError("fp8_forward needs d_model, d_inner and n_head * d_head to be multiples of 128")
         for i in range(L):
@@ -538,7 +545,11 @@ class MemTransformerLM(nn.Module):
                 nw = ops.signbits_words(TB, DI, D, a.stride(0), w["w1"].stride(0), DI)
                 if nw > 0 and ops.signbits_words(TB, DI, D, D, D, DI) > 0:
                     hbits = torch.empty(nw, device=dev, dtype=torch.int32)
-            if hbits is not None:
+            zff = None
+            if gelu:          # non-default activation: plain Linear, then the element-wise GELU + dropout pair
+                zff = ops.gemm_nt(a, w["w1"], bias=w["b1"])
+                hid = ops.gelu_fwd(zff, drop_p=p, drop_seed=ss(s0 + 2))
+            elif hbits is not None:
                 hid = ops.gemm_nt(a, w["w1"], bias=w["b1"], relu=True, drop_p=p, drop_seed=ss(s0 + 2), sign_bits_out=hbits)
             else:
                 hid = lin(a, "w1", bias=w["b1"], relu=True, drop_p=p, drop_seed=ss(s0 + 2))     # K8
@@ -550,7 +561,8 @@ class MemTransformerLM(nn.Module):
             if need_grad:
                 sv.h.append(h); sv.cat.append(cat); sv.qkv.append(qkv); sv.rd.append(rd); sv.vec.append(vec)
                 sv.lse.append(lse); sv.qs.append(qs); sv.z1.append(z1); sv.mu1.append(mu1); sv.rs1.append(rs1)
-                sv.a.append(a); sv.hid.append(hid); sv.hbits.append(hbits); sv.z2.append(z2); sv.mu2.append(mu2); sv.rs2.append(rs2)
+                sv.a.append(a); sv.hid.append(hid); sv.hbits.append(hbits); sv.zff.append(zff); sv.z2.append(z2)
+                sv.mu2.append(mu2); sv.rs2.append(rs2)
             if want_kv:
                 kv_out.append(qkv)
             h = y
@@ -767,7 +779,9 @@ class MemTransformerLM(nn.Module):
                 gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)), group=cgrp))
             wgrad(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
             hb = sv.hbits[i]
-            if hb is not None and ops.signbits_words(TB, DI, D, dz2m.stride(0), sh[f"w2_t{i}"].stride(0), DI) == hb.numel():
+            if sv.zff[i] is not None:          # GELU: dz = dhid_raw * keep/(1-p) * gelu'(z)
+                dhid = ops.gelu_bwd(ops.gemm_nt(dz2m, sh[f"w2_t{i}"]), sv.zff[i], drop_p=p, drop_seed=ss(s0 + 2))
+            elif hb is not None and ops.signbits_words(TB, DI, D, dz2m.stride(0), sh[f"w2_t{i}"].stride(0), DI) == hb.numel():
                 dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_bits=hb, mask_scale=inv_keep)
             else:
                 dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)

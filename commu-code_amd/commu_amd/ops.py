@@ -426,6 +426,25 @@ def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, 
     return dz, part[:nblk]
 
 
+def gelu_fwd(z, drop_p=0.0, drop_seed=0, out=None):
+    """out = dropout(gelu(z)) (exact erf form); z bf16 2-D.  Non-default FFN activation (commu_hip.h)."""
+    rows, cols = z.shape
+    if out is None:
+        out = torch.empty(rows, z.stride(0), device=z.device, dtype=BF16)[:, :cols]
+    call("commu_gelu_fwd", _p(z), z.stride(0), _p(out), out.stride(0), rows, cols, int(drop_seed), float(drop_p), _s())
+    return out
+
+
+def gelu_bwd(dy, z, drop_p=0.0, drop_seed=0, out=None):
+    """dz = dy * keep/(1-p) * gelu'(z)."""
+    rows, cols = z.shape
+    if out is None:
+        out = torch.empty(rows, z.stride(0), device=z.device, dtype=BF16)[:, :cols]
+    call("commu_gelu_bwd", _p(dy), dy.stride(0), _p(z), z.stride(0), _p(out), out.stride(0), rows, cols, int(drop_seed),
+         float(drop_p), _s())
+    return out
+
+
 class ColsumGroup:
     """Collects the final column-sum passes of a backward step (bias, LayerNorm-parameter and shared attention-bias
     gradients) and runs them as ONE launch (commu_colsum_group_f32): sources that add into the same output are walked by

@@ -1324,6 +1324,54 @@ extern "C" int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStre
     return 0;
 }
 
+// GELU as a NON-DEFAULT FFN activation (the reference's PositionwiseFF is Linear-ReLU-Dropout-Linear-Dropout,
+// model.py:163-169; BASELINE.json's north star names a GELU-FFN): exact erf form of torch.nn.functional.gelu, as an
+// element-wise pair around the plain Linear GEMMs -- out = dropout(gelu(z)), dz = dy * keep/(1-p) * gelu'(z) -- with the
+// same counter-based mask as a GEMM epilogue at that site (index m * cols + n).  Not on the headline path.
+__global__ __launch_bounds__(256) void gelu_kernel(const bf16* __restrict__ z, int ldz, const bf16* __restrict__ dy, int lddy,
+                                                   bf16* __restrict__ out, int ldo, int rows, int cols, unsigned drop_seed,
+                                                   unsigned drop_thr, float drop_scale) {
+    const unsigned key = mix32(salted(drop_seed));
+    const int cg = (cols + 7) / 8;
+    const size_t total = (size_t)rows * cg;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const int m = (int)(t / cg), n0 = (int)(t % cg) * 8;
+        const bf16x8 zv = ld_bf16x8(z + (size_t)m * ldz + n0);
+        bf16x8 gv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (dy != nullptr) gv = ld_bf16x8(dy + (size_t)m * lddy + n0);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = bf2f(zv[e]);
+            const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+            float v = dy == nullptr ? x * cdf : bf2f(gv[e]) * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x));
+            if (drop_thr) v = mix32k((unsigned)m * (unsigned)cols + (unsigned)(n0 + e), key) >= drop_thr ? v * drop_scale : 0.f;
+            o[e] = f2bf(n0 + e < cols ? v : 0.f);
+        }
+        st_bf16x8(out + (size_t)m * ldo + n0, o);
+    }
+}
+static int gelu_launch(const void* z, int ldz, const void* dy, int lddy, void* out, int ldo, int rows, int cols,
+                       unsigned drop_seed, float drop_p, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int c8 = (cols + 7) & ~7;
+    if ((ldz % 8) || (ldo % 8) || ldz < c8 || ldo < c8 || (dy != nullptr && ((lddy % 8) || lddy < c8))) return -22;
+    const size_t total = (size_t)rows * (c8 / 8);
+    COMMU_LAUNCH(gelu_kernel, dim3(cap_blocks((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)z, ldz,
+                 (const bf16*)dy, lddy, (bf16*)out, ldo, rows, cols, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int commu_gelu_fwd(const void* z, int ldz, void* out, int ldo, int rows, int cols, unsigned drop_seed, float drop_p,
+                              hipStream_t stream) {
+    return gelu_launch(z, ldz, nullptr, 0, out, ldo, rows, cols, drop_seed, drop_p, stream);
+}
+extern "C" int commu_gelu_bwd(const void* dy, int lddy, const void* z, int ldz, void* dz, int lddz, int rows, int cols,
+                              unsigned drop_seed, float drop_p, hipStream_t stream) {
+    if (dy == nullptr) return -22;
+    return gelu_launch(z, ldz, dy, lddy, dz, lddz, rows, cols, drop_seed, drop_p, stream);
+}
+
 extern "C" int commu_cast_bf16_f32(const void* in, float* out, size_t n, hipStream_t stream) {
     if (n == 0) return 0;
     COMMU_LAUNCH(cast_bf16_f32_kernel, dim3(cap_blocks((n + 255) / 256)), dim3(256), 0, stream,

@@ -162,6 +162,15 @@ int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D
 int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, const float* beta, void* y, int ldy,
                         float* mean, float* rstd, int rows, int D, float eps, void* y_drop, int ldyd,
                         unsigned drop_seed, float drop_p, hipStream_t stream);
+/* GELU (exact erf form of torch.nn.functional.gelu) as a NON-DEFAULT FFN activation -- the reference's PositionwiseFF uses
+ * ReLU (model.py:163-169), which stays the default and the parity mode; BASELINE.json's north star names a GELU-FFN:
+ *   fwd: out[m,n] = dropout(gelu(z[m,n]))          bwd: dz[m,n] = dy[m,n] * keep/(1-p) * gelu'(z[m,n])
+ * bf16 rows, row strides % 8 == 0 and >= cols rounded up to 8 (pad columns are written as zero); the dropout mask is the
+ * GEMM epilogue's at that site: keep(drop_seed, m * cols + n). */
+int commu_gelu_fwd(const void* z, int ldz, void* out, int ldo, int rows, int cols, unsigned drop_seed, float drop_p,
+                   hipStream_t stream);
+int commu_gelu_bwd(const void* dy, int lddy, const void* z, int ldz, void* dz, int lddz, int rows, int cols,
+                   unsigned drop_seed, float drop_p, hipStream_t stream);
 int commu_layernorm_bwd_nblocks(int rows);
 /* part: [nblocks][3][D] partial column sums of (dy*xhat, dy, dz) */
 /* dz_masked (optional): dz through the dropout that followed the Linear feeding this LayerNorm

@@ -164,7 +164,11 @@ def ff_block(p: Dict[str, Tensor], li: int, a: Tensor, drop=_nodrop) -> Tensor:
     # (parity tests of a reduced-precision build may inject ITS ReLU gates -- `drop.relu_gate(li, z)` -> 0/1 tensor --
     #  so that a pre-activation within rounding of 0 does not flip a whole gradient term; default: the reference's ReLU)
     gate = getattr(drop, "relu_gate", None)
-    f = drop(("hid", li), torch.relu(z) if gate is None else z * gate(li, z))
+    if getattr(drop, "activation", "relu") == "gelu":      # non-default option of the build (the reference has ReLU only)
+        act = torch.nn.functional.gelu(z)
+    else:
+        act = torch.relu(z) if gate is None else z * gate(li, z)
+    f = drop(("hid", li), act)
     f = drop(("out", li), f @ p[pre + "pos_ff.CoreNet.3.weight"].t() + p[pre + "pos_ff.CoreNet.3.bias"])
     return layer_norm(a + f, p[pre + "pos_ff.layer_norm.weight"], p[pre + "pos_ff.layer_norm.bias"])
 

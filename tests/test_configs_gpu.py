@@ -89,6 +89,57 @@ def test_config_shape_loss_and_grads_vs_oracle(case):
     assert not bad, (tag, bad)
 
 
+def test_gelu_ffn_option_vs_oracle():
+    """model.ffn_activation = "gelu" (a non-default option: BASELINE.json's north star names a GELU-FFN, the reference's FFN
+    is ReLU): element-wise kernels against torch.nn.functional.gelu with the dropout mask injected, then per-token loss and
+    every gradient of a 2-layer model against the oracle with the same activation.  Never used for parity claims."""
+    from commu_amd import ops
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randn(300, 200, generator=g) * 1.5).to(torch.bfloat16)
+    dy = torch.randn(300, 200, generator=g).to(torch.bfloat16)
+    p, seed = 0.25, 4711
+    keep = ops.dropout_keep_mask(seed, 300 * 200, p).view(300, 200).float()
+    zl = z.float().requires_grad_(True)
+    ref = torch.nn.functional.gelu(zl) * keep / (1 - p)
+    ref.backward(dy.float())
+    zd = torch.zeros(300, 208, dtype=torch.bfloat16, device=DEV)
+    zd[:, :200] = z.to(DEV)
+    out = ops.gelu_fwd(zd[:, :200], drop_p=p, drop_seed=seed)
+    dyd = torch.zeros(300, 208, dtype=torch.bfloat16, device=DEV)
+    dyd[:, :200] = dy.to(DEV)
+    dz = ops.gelu_bwd(dyd[:, :200], zd[:, :200], drop_p=p, drop_seed=seed)
+    assert float((out.float().cpu() - ref.detach()).abs().max()) < 2e-2 * float(ref.abs().max())
+    assert float((dz.float().cpu() - zl.grad).abs().max()) < 2e-2 * float(zl.grad.abs().max())
+
+    L, H, D, DI, T, B = 2, 4, 128, 256, 96, 3
+    model, cfg, s, params = build(L, H, D, DI, T, 0, seed=5)
+    model.ffn_activation = "gelu"
+    model.eval()
+    data = torch.randint(1, 729, (T, B), generator=g)
+    target = torch.randint(1, 729, (T, B), generator=g)
+    reset = torch.zeros(B, dtype=torch.bool)
+    oparams = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+
+    class Gelu:
+        activation = "gelu"
+
+        def __call__(self, site, x):
+            return x
+    model.zero_grad()
+    loss, _ = model(data.to(DEV), target.to(DEV), reset.to(DEV), None)
+    nll, _ = X.forward_loss(oparams, s, data, target, reset, None, 0, False, drop=Gelu())
+    err = (loss.detach().float().cpu() - nll.detach()).abs()
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 8e-3
+    relu_nll, _ = X.forward_loss(params, s, data, target, reset, None, 0, False)
+    assert float((relu_nll - nll.detach()).abs().max()) > 1e-3          # (the option really changes the function)
+    nll.mean().backward()
+    loss.float().mean().backward()
+    for name, prm in model.named_parameters():
+        if name in oparams and oparams[name].grad is not None:
+            a, b = prm.grad.detach().float().cpu().flatten(), oparams[name].grad.flatten()
+            assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) > 0.995, name
+
+
 def test_bench_shape_full_batch_columns_vs_oracle():
     """The headline shape AT THE BENCH BATCH (64 columns x 1024 tokens, eval mode): the paths that depend on the grid
     size -- grouped / eight-phase GEMMs over 65 536 rows, the fused band pass, the XCD tile order, the 256-row attention
