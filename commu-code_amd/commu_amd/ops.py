@@ -48,11 +48,25 @@ def _mix32k(x, key):
 
 
 def dropout_keep_mask(seed: int, n: int, p: float, device="cpu"):
-    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests; common.h drop_keep)."""
-    key = int(_mix32(torch.tensor(int(seed) & 0xFFFFFFFF, dtype=torch.int64)))
-    x = _mix32k(torch.arange(n, dtype=torch.int64, device=device), key)
-    thr = min(int(p * 4294967296.0), 4294967295) if p > 0 else 0
-    return x >= thr
+    """The kernels' keep mask for element indices 0..n-1 (reference implementation for tests; common.h drop_word): one
+    hash word per two consecutive indices -- two 24-bit multiply-add rounds around a xor-shift, keyed by mix32(seed) --, the
+    even index takes the low 16 bits, the odd one the high 16, against round(p * 65536).  Kept values are scaled by
+    1 / (1 - thr / 65536) in the kernels (within 8e-6 of 1 / (1 - p))."""
+    M32, M24 = 0xFFFFFFFF, 0xFFFFFF
+    key = int(_mix32(torch.tensor(int(seed) & M32, dtype=torch.int64)))
+    k2 = (key * 0x85EBCA6B + 0x6A09E667) & M32
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    q = idx >> 1
+    y = ((q & M24) * 0xD2B74B + key) & M32
+    y = (((q >> 24) & M24) * 0xB5297A + y) & M32
+    y = y ^ (y >> 13)
+    w = ((y & M24) * 0x9E3779 + k2) & M32
+    w = w ^ (w >> 15)
+    half = torch.where((idx & 1).bool(), w >> 16, w & 0xFFFF)
+    thr = min(65535, max(1, int(p * 65536.0 + 0.5))) if p > 0 else 0
+    return half >= thr
+
+
 BF16 = torch.bfloat16
 F32 = torch.float32
 

@@ -97,7 +97,41 @@ __device__ __forceinline__ unsigned mix32k(unsigned idx, unsigned key) {
 }
 // (the key itself is mixed first -- wave-uniform, so it costs scalar instructions once -- because seeds that differ
 //  only in a few low bits would otherwise change the second round's input by a near-constant)
-__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned idx, unsigned thr) { return mix32k(idx, mix32(seed)) >= thr; }
+// Element-wise dropout sites (round 4): ONE hash word per TWO consecutive element indices, on full-rate 24-bit multiply-adds
+// (the keyed lowbias32 above costs two quarter-rate 32-bit multiplies per ELEMENT: a GEMM epilogue at K = 512 could not hide
+// it, +17-25 us per launch).  word(q = idx >> 1) = two multiply rounds around a xor-shift, keyed by mix32(seed) (scalar work);
+// the even index takes the low 16 bits, the odd one the high 16, compared with thr16 = round(p * 65536); kept values are
+// scaled by 1 / (1 - thr16 / 65536), the exact keep probability.  Host mirror: ops.dropout_keep_mask.
+struct DropKey {
+    unsigned key, k2;
+};
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }
+__device__ __forceinline__ DropKey drop_key(unsigned seed) {
+    DropKey k;
+    k.key = mix32(seed);
+    k.k2 = k.key * 0x85EBCA6Bu + 0x6A09E667u;
+    return k;
+}
+__device__ __forceinline__ unsigned drop_word(unsigned q, DropKey k) {
+    unsigned y = mad24(q >> 24, 0xB5297Au, mad24(q, 0xD2B74Bu, k.key));
+    y ^= y >> 13;
+    const unsigned w = mad24(y, 0x9E3779u, k.k2);
+    return w ^ (w >> 15);
+}
+__device__ __forceinline__ bool drop_half(unsigned w, unsigned odd, unsigned thr16) {
+    return (odd ? (w >> 16) : (w & 0xFFFFu)) >= thr16;
+}
+__device__ __forceinline__ bool drop_keep(DropKey k, unsigned idx, unsigned thr16) {
+    return drop_half(drop_word(idx >> 1, k), idx & 1u, thr16);
+}
+__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned idx, unsigned thr16) { return drop_keep(drop_key(seed), idx, thr16); }
+// host side: 16-bit threshold of a rate (0: off) and the exact keep scale
+static inline unsigned drop_threshold16(float p) {
+    if (p <= 0.f) return 0u;
+    const unsigned t = (unsigned)((double)p * 65536.0 + 0.5);
+    return t < 1u ? 1u : (t > 65535u ? 65535u : t);
+}
+static inline float drop_keep_scale16(unsigned thr16) { return 1.f / (1.f - (float)thr16 / 65536.f); }
 
 // Seed salt (one copy per translation unit): every dropout site uses `seed argument + g_seed_salt`.  Eager launches never
 // touch it (0: the seed argument alone decides).  A training step replayed from a hipGraph has its seed ARGUMENTS

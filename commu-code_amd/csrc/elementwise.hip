@@ -23,7 +23,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
     bf16* dst = out + (size_t)m * ldo;
     const int Dz = min(ldo, (D + 63) & ~63);          // zero-padding contract: columns [D, Dz) are written as 0
     if ((D & 7) == 0 && (ldo & 7) == 0) {          // 8 columns per lane: two 16-byte loads, one 16-byte store
-        const unsigned key = mix32(salted(drop_seed));
+        const DropKey key = drop_key(salted(drop_seed));
         for (int c = lane * 8; c < Dz; c += 512) {
             bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
             if (c < D) {
@@ -31,7 +31,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* _
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = bad ? __builtin_nanf("") : (e < 4 ? v0[e & 3] : v1[e & 3]) * scale;
-                    if (drop_thr) x = mix32k((unsigned)m * (unsigned)D + (unsigned)(c + e), key) >= drop_thr ? x * drop_scale : 0.f;
+                    if (drop_thr) x = drop_keep(key, (unsigned)m * (unsigned)D + (unsigned)(c + e), drop_thr) ? x * drop_scale : 0.f;
                     o[e] = f2bf(x);
                 }
             }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void embed_bwd_runs_kernel(
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);          // this wave's chunk
     const long long lo = (long long)c * EMB_CHUNK, hi = min((long long)ntok, lo + EMB_CHUNK);
     if (lo >= hi) return;
-    const unsigned key = mix32(salted(drop_seed));
+    const DropKey key = drop_key(salted(drop_seed));
     // id of the first token of the chunk: the largest v with offs[v] <= lo (binary search over the V + 1 offsets)
     int v = 0;
     {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void embed_bwd_runs_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float f = bf2f(x[u][cc][e]);
-                    if (drop_thr) f = mix32k((unsigned)mm[u] * (unsigned)D + (unsigned)(col + e), key) >= drop_thr ? f * drop_scale : 0.f;
+                    if (drop_thr) f = drop_keep(key, (unsigned)mm[u] * (unsigned)D + (unsigned)(col + e), drop_thr) ? f * drop_scale : 0.f;
                     acc[cc][e] += f;
                 }
             }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const int r0 = blockIdx.x * LNB_ROWS + w * LNB_WROWS;
     const int nr = min(LNB_WROWS, rows - r0);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned key = mix32(salted(drop_seed));
+    const DropKey key = drop_key(salted(drop_seed));
     const float invD = 1.f / (float)D;
     bf16x8 vz[2][NC], vd[2][NC], nz[2][NC], nd[2][NC];
     float vmu[2], vrs[2], nmu[2], nrs[2];
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                         o[e] = f2bf(v);
                         if (dzm != nullptr) {
                             // gradient w.r.t. the pre-dropout Linear output that fed this LayerNorm
-                            const bool keep = mix32k((unsigned)row * (unsigned)D + (unsigned)(col + e), key) >= drop_thr;
+                            const bool keep = drop_keep(key, (unsigned)row * (unsigned)D + (unsigned)(col + e), drop_thr);
                             om[e] = f2bf(keep ? v * drop_scale : 0.f);
                             az[c][e] += bf2f(om[e]);
                         } else {
@@ -893,17 +893,14 @@ static inline unsigned cap_blocks(size_t want) {
     return (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
 }
 
-static inline unsigned drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
-    return p <= 0.f ? 0u : (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
-}
+static inline unsigned drop_threshold(float p) { return drop_threshold16(p); }          // (common.h: 16-bit, one word per two elements)
 
 extern "C" int commu_embed_fwd(const int64_t* tok, const float* E, void* out, int ldo, int ntok, int D, int V,
                                float scale, unsigned drop_seed, float drop_p, hipStream_t stream) {
     if (ntok <= 0) return 0;
     if (D % 4) return -22;
     COMMU_LAUNCH(embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, stream, tok, E, (bf16*)out,
-                       ldo, ntok, D, V, scale, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                       ldo, ntok, D, V, scale, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -913,7 +910,7 @@ extern "C" int commu_embed_bwd(const int64_t* tok, const void* dX, int ldx, floa
                                hipStream_t stream) {
     if (D > 1024) return -22;
     COMMU_LAUNCH(embed_bwd_kernel, dim3(V), dim3(256), 0, stream, tok, (const bf16*)dX, ldx, dE,
-                       ntok, D, scale, accumulate, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                       ntok, D, scale, accumulate, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -1020,10 +1017,10 @@ extern "C" int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, 
         const dim3 grid((nchunks + 3) / 4);
         if (D <= 512)
             COMMU_LAUNCH(embed_bwd_runs_kernel<1>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, ws, ntok, D,
-                         V, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                         V, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
         else
             COMMU_LAUNCH(embed_bwd_runs_kernel<2>, grid, dim3(256), 0, stream, perm, offs, (const bf16*)dX, ldx, ws, ntok, D,
-                         V, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                         V, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     }
     COMMU_LAUNCH(embed_bwd_fold_kernel, dim3(V), dim3(256), 0, stream, offs, ws, dE, D, V, scale, accumulate);
     COMMU_LAUNCH_CHECK();
@@ -1035,7 +1032,7 @@ extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K,
     const int n = K * (D / 2);
     if (n <= 0) return 0;
     COMMU_LAUNCH(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_freq, (bf16*)out,
-                       ld, K, D, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                       ld, K, D, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -1050,7 +1047,7 @@ extern "C" int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, c
         return -22;
     COMMU_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16*)z,
                        ldz, gamma, beta, (bf16*)y, ldy, mean, rstd, rows, D, eps, (bf16*)y_drop, ldyd, drop_seed,
-                       drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                       drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -1069,11 +1066,11 @@ extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int 
     if (D <= 512)
         COMMU_LAUNCH(layernorm_bwd_kernel<1>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
                      (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,
-                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     else
         COMMU_LAUNCH(layernorm_bwd_kernel<2>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
                      (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,
-                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -1331,7 +1328,7 @@ extern "C" int commu_cast_f32_bf16(const float* in, void* out, size_t n, hipStre
 __global__ __launch_bounds__(256) void gelu_kernel(const bf16* __restrict__ z, int ldz, const bf16* __restrict__ dy, int lddy,
                                                    bf16* __restrict__ out, int ldo, int rows, int cols, unsigned drop_seed,
                                                    unsigned drop_thr, float drop_scale) {
-    const unsigned key = mix32(salted(drop_seed));
+    const DropKey key = drop_key(salted(drop_seed));
     const int cg = (cols + 7) / 8;
     const size_t total = (size_t)rows * cg;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
@@ -1345,7 +1342,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const bf16* __restrict__ z, i
             const float x = bf2f(zv[e]);
             const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
             float v = dy == nullptr ? x * cdf : bf2f(gv[e]) * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x));
-            if (drop_thr) v = mix32k((unsigned)m * (unsigned)cols + (unsigned)(n0 + e), key) >= drop_thr ? v * drop_scale : 0.f;
+            if (drop_thr) v = drop_keep(key, (unsigned)m * (unsigned)cols + (unsigned)(n0 + e), drop_thr) ? v * drop_scale : 0.f;
             o[e] = f2bf(n0 + e < cols ? v : 0.f);
         }
         st_bf16x8(out + (size_t)m * ldo + n0, o);
@@ -1358,7 +1355,7 @@ static int gelu_launch(const void* z, int ldz, const void* dy, int lddy, void* o
     if ((ldz % 8) || (ldo % 8) || ldz < c8 || ldo < c8 || (dy != nullptr && ((lddy % 8) || lddy < c8))) return -22;
     const size_t total = (size_t)rows * (c8 / 8);
     COMMU_LAUNCH(gelu_kernel, dim3(cap_blocks((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)z, ldz,
-                 (const bf16*)dy, lddy, (bf16*)out, ldo, rows, cols, drop_seed, drop_threshold(drop_p), 1.f / (1.f - drop_p));
+                 (const bf16*)dy, lddy, (bf16*)out, ldo, rows, cols, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -620,7 +620,7 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
             return -22;
         G8Args g8{(const bf16*)A, (const bf16*)B, C, lda, ldb, ldc, M, N, K, (M + 255) / 256, (N + 255) / 256,
                   bias, nullptr, 0, (const bf16*)relu_mask, 0, flags, drop_seed,
-                  (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0), 1.f / (1.f - drop_p), mask_scale, 0, 0};
+                  drop_threshold16(drop_p), drop_keep_scale16(drop_threshold16(drop_p)), mask_scale, 0, 0};
         return launch_gemm8_nt(g8, stream);
     }
     const bool skinny = M <= 64 && batch == 1 && bs.tri_B == 0 && (K % 128) == 0 && K <= 1024 && N >= 32 &&
@@ -671,7 +671,7 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
         // large-M Linear shapes: persistent 256 x 256 x 64 eight-phase kernel (gemm8.hip)
         G8Args g8{(const bf16*)A, (const bf16*)B, C, lda, ldb, ldc, M, N, K, (M + 255) / 256, (N + 255) / 256,
                   bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags, drop_seed,
-                  (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0), 1.f / (1.f - drop_p), mask_scale, 0, 0};
+                  drop_threshold16(drop_p), drop_keep_scale16(drop_threshold16(drop_p)), mask_scale, 0, 0};
         return launch_gemm8_nt(g8, stream);
     }
     const bool narrow = (N <= 64);
@@ -683,8 +683,8 @@ static int launch_gemm_nt(const void* A, int lda, const void* B, int ldb, void* 
     const int bn = narrow ? 64 : (tall ? 128 : (big ? 256 : 128)), bm = (big || tall) ? 256 : 128;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     dim3 grid(tiles_m * tiles_n, batch);
-    const unsigned drop_thr = (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0);
-    const float drop_scale = 1.f / (1.f - drop_p);
+    const unsigned drop_thr = drop_threshold16(drop_p);          // 16-bit threshold, exact keep scale (common.h)
+    const float drop_scale = drop_keep_scale16(drop_thr);
 #define NT_LAUNCH(F32, NBW, BKT)                                                                                   \
     COMMU_LAUNCH((gemm_nt_kernel<F32, NBW, BKT>), grid, dim3(256), 0, stream, (const bf16*)A, lda, (const bf16*)B, \
                  ldb, C, ldc, M, N, K, bias, (const bf16*)resid, ldr, (const bf16*)relu_mask, ldm, flags,          \

@@ -127,11 +127,15 @@ __device__ __forceinline__ void g8_store(const G8Args& a, f32x4 (&acc)[4][8], in
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (flags & COMMU_EPI_DROPOUT) {
+                if (flags & COMMU_EPI_DROPOUT) {          // (N even, n a multiple of 8: one word per two columns)
+                    const DropKey dk = drop_key(salted(a.drop_seed));
+                    const unsigned q0 = ((unsigned)m * (unsigned)N + (unsigned)n) >> 1, thr_hi = a.drop_thr << 16;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[e] = drop_keep(salted(a.drop_seed), (unsigned)m * (unsigned)N + (unsigned)(n + e), a.drop_thr)
-                                   ? v[e] * a.drop_scale : 0.f;
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const unsigned w = drop_word(q0 + (unsigned)e2, dk);
+                        v[2 * e2] = (unsigned short)w >= (unsigned short)a.drop_thr ? v[2 * e2] * a.drop_scale : 0.f;
+                        v[2 * e2 + 1] = w >= thr_hi ? v[2 * e2 + 1] * a.drop_scale : 0.f;
+                    }
                 }
                 if (flags & COMMU_EPI_RESID) {
 #pragma unroll
@@ -207,9 +211,17 @@ __device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (flags & COMMU_EPI_DROPOUT) {
-            const unsigned key = mix32(salted(a.drop_seed)), i0 = (unsigned)m * (unsigned)N + (unsigned)n;
+            // one hash word per TWO elements (common.h drop_word): the lane's 8 columns start at an even flat index (n is a
+            // multiple of 8 and the launcher only takes an even N with COMMU_EPI_DROPOUT): four words for eight elements
+            const DropKey dk = drop_key(salted(a.drop_seed));
+            const unsigned q0 = ((unsigned)m * (unsigned)N + (unsigned)n) >> 1;
+            const unsigned thr_hi = a.drop_thr << 16;          // (high half: whole-word compare; low half: 16-bit compare)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = mix32k(i0 + (unsigned)e, key) >= a.drop_thr ? v[e] * a.drop_scale : 0.f;
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const unsigned w = drop_word(q0 + (unsigned)e2, dk);
+                v[2 * e2] = (unsigned short)w >= (unsigned short)a.drop_thr ? v[2 * e2] * a.drop_scale : 0.f;
+                v[2 * e2 + 1] = w >= thr_hi ? v[2 * e2 + 1] * a.drop_scale : 0.f;
+            }
         }
         if (BITS == 2) {          // ReLU backward: bit ? C * mask_scale : 0  (sign-extended bit AND-ed onto the product)
 #pragma unroll
@@ -761,6 +773,7 @@ bool gemm8_nt_eligible(int M, int N, int K, int lda, int ldb, int batch, int tri
     if (batch != 1 || tri_B != 0) return false;
     if ((flags & COMMU_EPI_RESID) && (flags & COMMU_EPI_RELUMASK)) return false;          // one auxiliary operand per call
     if (M < 1024 || N < 256 || K < 128 || (K % 64) != 0) return false;
+    if ((flags & COMMU_EPI_DROPOUT) && (N & 1)) return false;          // the pipelined epilogue pairs columns 2k, 2k+1 per hash word
     // fewer output tiles than CUs: the persistent kernel's fixed cost (~20 us) is not amortised and three quarters of the
     // chip idle -- the 128 x 128 / 256 x 128 tiled kernels take these (8192 x 512 x 512: 14 us against 22 us)
     if (((M + 255) / 256) * ((N + 255) / 256) < 256 && !getenv("COMMU_GEMM8_ALWAYS")) return false;

@@ -231,7 +231,7 @@ extern "C" int commu_gemm_nt_mxfp8(const void* A, int lda, const void* SA, int l
     if (((flags & COMMU_EPI_BIAS) && !bias) || ((flags & COMMU_EPI_RESID) && !resid)) return -22;
     F8Args a = {(const unsigned char*)A, (const unsigned char*)SA, (const unsigned char*)B, (const unsigned char*)SB, (bf16*)C,
                 bias, (const bf16*)resid, lda, ldsa, ldb, ldsb, ldc, ldr, M, N, K, flags, drop_seed,
-                (unsigned)fmin(4294967295.0, (double)drop_p * 4294967296.0), 1.f / (1.f - drop_p)};
+                drop_threshold16(drop_p), drop_keep_scale16(drop_threshold16(drop_p))};
     if (!(flags & COMMU_EPI_DROPOUT) || drop_p <= 0.f) a.flags &= ~COMMU_EPI_DROPOUT;
     const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
     COMMU_LAUNCH(gemm_nt_mxfp8_kernel, dim3(tiles), dim3(256), 0, stream, a);
