@@ -127,7 +127,8 @@ def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
         def run(n):          # (ForcedDecoder.run's loop with a fixed iteration count: done flags polled one window late, no stall)
             done, live, pending = 0, True, False
             while done < n:
-                dec.run_iterations(dec.POLL, graph)
+                # (what ForcedDecoder.run knows: the bound of the memory lengths and that all sequences are alive)
+                dec.run_iterations(dec.POLL, graph, klen_bound=klen0 + 16 + done + dec.POLL, live_rows=B)
                 done += dec.POLL
                 if pending:
                     live = live and not bool(dec.poll_result()[:, 5].all())

@@ -117,6 +117,8 @@ PROTOTYPES = {
     "commu_sample_topk_topp": [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_f, c_i, c_f, c_p, c_p, c_i, c_p],
     "commu_decode_kv_append": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_decode_attn": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p],
+    "commu_decode_attn_split": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i,
+                                c_i, c_p, c_p, c_p],
     "commu_decode_advance": [c_p, c_p, c_i, c_i, c_p],
     "commu_decode_tail_supported": [c_i, c_i, c_i, c_i],
     "commu_decode_tail_sync_words": [],

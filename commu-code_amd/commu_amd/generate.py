@@ -51,6 +51,7 @@ class DecodeState:
         fl = model._ensure_flat()
         dev = fl["dev"]
         self.model, self.B, self.Lmax = model, B, Lmax
+        self.attn_splits, self.split_ws, self.split_cnt = 1, None, None
         # kernel-side dimensions (zero-padded when the model's are not multiples of 64 / 32, see model.py)
         L, D = model.n_layer, model._Dp
         H, DH = model.n_head, model._DHp
@@ -95,6 +96,22 @@ class DecodeState:
             self.vc[i, :, :, :T0].copy_(kv[:, :, 2].permute(1, 2, 0, 3))
         self.klen.fill_(T0)
 
+    def _attn(self, i, u, vb, active, B, H, DH, scale):
+        """Cached attention of layer i (K/V append fused in).  attn_splits > 1: the keys of a (sequence, head) pair over
+        several workgroups (long memories, few live sequences); pairs with fewer than 512 keys run unsplit either way."""
+        if self.attn_splits > 1:
+            if self.split_ws is None:
+                self.split_ws = torch.empty(B * H * 16 * (DH + 2), device=self.qkv.device, dtype=torch.float32)
+                self.split_cnt = torch.zeros(B * H, device=self.qkv.device, dtype=torch.int32)
+            call("commu_decode_attn_split", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
+                 _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
+                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, int(self.attn_splits),
+                 _p(self.split_ws), _p(self.split_cnt), _s())
+        else:
+            call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
+                 _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
+                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, _s())
+
     def step(self, tokens: torch.Tensor, active: Optional[torch.Tensor], keep: Optional[torch.Tensor], want_logits=True):
         """One decode step for the sequences with active[b] != 0; klen advances where keep[b] != 0 (keep = None: the
         caller advances the lengths itself, ForcedDecoder does it in its book-keeping kernel).
@@ -121,9 +138,7 @@ class DecodeState:
             else:                     # h = LN2(z2) of the layer below, computed on the fly and stored
                 h = torch.empty_like(z2)
                 ops.gemm_nt_ln(z2, ln2.weight, ln2.bias, w["qkv"], out=self.qkv, a_out=h, eps=ln2.eps)
-            call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
-                 _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
-                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, _s())      # (K/V append fused in)
+            self._attn(i, u, vb, active, B, H, DH, scale)                                    # (K/V append fused in)
             z1 = ops.gemm_nt(self.vec, w["o"], resid=h)
             ln1 = lay.dec_attn.layer_norm
             a = torch.empty_like(z1)
@@ -186,9 +201,7 @@ class DecodeState:
         dst = self.logits          # (the logits launch skips the rows of the sequences that did not step)
         for i in range(L):
             w, lay = ws[i], m.layers[i]
-            call("commu_decode_attn", _p(self.qkv), self.qkv.stride(0), _p(self.kc[i]), _p(self.vc[i]),
-                 _p(self.rd[i]), self.rd[i].stride(0), _p(u), _p(vb), _p(self.klen), _p(active),
-                 _p(self.vec), self.vec.stride(0), B, H, DH, self.Lmax, scale, 1, _s())
+            self._attn(i, u, vb, active, B, H, DH, scale)
             last = i == L - 1
             if last and not want_logits:
                 break
@@ -258,6 +271,7 @@ class ForcedDecoder:
         self.ld_trace = 2 * (self.generation_length + 2) if record_trace else 0
         self.trace = torch.zeros(B, self.ld_trace, dtype=i32, device=dev) if record_trace else None
         self.graph = None
+        self.graph_long = None
         self.n_cond = 0
 
     # ---- one loop iteration = decide (pre) -> model step -> sampling step -> book-keeping (post), as kernel launches
@@ -297,27 +311,45 @@ class ForcedDecoder:
         self.pre()
         self.body(want_probs)
 
-    def build_graph(self):
+    # The split-key iteration graph pays off when FEW sequences are still alive at LONG memories (one workgroup per
+    # (sequence, head) pair then streams ~1 MB alone while most of the chip idles); with all 64 sequences alive the plain
+    # kernel already fills the chip and the in-launch combine only costs (measured: 0.60 against 0.37 ms per iteration).
+    # (tests/probes/decode_long_rows.py, 64 sequences to completion: no split 77.8 k tokens/s; rows <= 16 / 24 / 32 / 48 with
+    #  8 splits 88.9 / 93.8 / 89.2 / 85.2 k; rows <= 32 with 4 splits 93.0 k and the 256-sequence stream 107 k)
+    LONG_KLEN = 768        # memories beyond this ...
+    LONG_ROWS = 32         # ... and at most this many live sequences
+    LONG_SPLITS = 4
+
+    def build_graph(self, long: bool = False):
         """Capture [body, pre].  The warm-up run that the capture needs (allocator pools, lazy module state) is made
-        on a scratch copy of every buffer the iteration mutates, which is restored afterwards."""
+        on a scratch copy of every buffer the iteration mutates, which is restored afterwards.  long: the variant for
+        long memories (commu_decode_attn_split: up to LONG_SPLITS workgroups per (sequence, head) pair)."""
         st = self.state
         # (the K/V rows the warm-up appends at klen are rewritten by the real run: the caches need no copy)
         bufs = (self.fsm, self.seq, self.wrong, st.klen, st.logits, self.tok, self.active, self.keep, self.draw, self.uni)
         saved = [t.clone() for t in bufs]
         tr = None if self.trace is None else self.trace.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self.body_pre()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.body_pre()
+        keep_splits, st.attn_splits = st.attn_splits, (self.LONG_SPLITS if long else 1)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.body_pre()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.body_pre()
+        finally:
+            st.attn_splits = keep_splits
         for dst, src in zip(bufs, saved):
             dst.copy_(src)
         if tr is not None:
             self.trace.copy_(tr)
-        return self.graph
+        if long:
+            self.graph_long = g
+        else:
+            self.graph = g
+        return g
 
     def load(self, encoded_metas: Sequence[Sequence[int]], input_datas, uniforms: Optional[np.ndarray] = None):
         """Conditioning of all B sequences: context [0] + meta[:n-1] into the caches (the n-th meta token is fed by
@@ -413,12 +445,25 @@ class ForcedDecoder:
         self._done_ev.synchronize()
         return self._done_pin.numpy().copy()
 
-    def run_iterations(self, n: int, use_graph: bool = True):
-        for _ in range(n):
-            if use_graph:
-                self.graph.replay()
-            else:
-                self.body_pre()
+    def run_iterations(self, n: int, use_graph: bool = True, klen_bound: int = 0, live_rows: Optional[int] = None):
+        """n iterations.  klen_bound: an upper bound of the memory lengths during them (0: unknown / short), live_rows: the
+        number of sequences still decoding (None: unknown = all): beyond LONG_KLEN with at most LONG_ROWS live sequences
+        the split-key iteration graph runs (built on first use)."""
+        long = klen_bound > self.LONG_KLEN and live_rows is not None and live_rows <= self.LONG_ROWS
+        if use_graph and long and getattr(self, "graph_long", None) is None:
+            self.build_graph(long=True)
+        g = self.graph_long if (use_graph and long) else self.graph
+        if not use_graph:
+            keep_splits, self.state.attn_splits = self.state.attn_splits, (self.LONG_SPLITS if long else 1)
+        try:
+            for _ in range(n):
+                if use_graph:
+                    g.replay()
+                else:
+                    self.body_pre()
+        finally:
+            if not use_graph:
+                self.state.attn_splits = keep_splits
 
     def run(self, use_graph: bool = True):
         try:
@@ -429,7 +474,7 @@ class ForcedDecoder:
             if not self.state.tail_ok or getattr(self, "_last_load", None) is None:
                 raise
             self.state.tail_ok = False
-            self.graph = None
+            self.graph = self.graph_long = None
             self.load(*self._last_load)
             self._run(use_graph)
 
@@ -437,12 +482,15 @@ class ForcedDecoder:
         if use_graph and self.graph is None:
             self.build_graph()
         self.pre()                                          # decision of the first iteration
-        it, pending = 0, False
+        it, pending, live = 0, False, None
         while it < self.generation_length + 1:
-            self.run_iterations(self.POLL, use_graph)
+            self.run_iterations(self.POLL, use_graph, klen_bound=self.n_cond + it + self.POLL, live_rows=live)
             it += self.POLL
-            if pending and bool(self.poll_result()[:, 5].all()):          # the records one window back: no stall
-                break
+            if pending:
+                rec = self.poll_result()                                  # the records one window back: no stall
+                if bool(rec[:, 5].all()):
+                    break
+                live = int((rec[:, 5] == 0).sum())
             self.poll_submit()
             pending = True
         torch.cuda.current_stream().synchronize()
@@ -534,10 +582,13 @@ class BatchedGenerator:
         results = {}                           # attempt -> its sequence if accepted, False if rejected
         n_ok, out = 0, None
         dec.run_iterations(dec.POLL, self.use_graph)
+        kb, nlive = 0, None                    # bound of the memory lengths, live slots (from the polled records)
         while out is None and any(a >= 0 for a in slot_attempt):
             dec.poll_submit()                  # the records after the window just queued ...
-            dec.run_iterations(dec.POLL, self.use_graph)          # ... are read while the next window runs
+            dec.run_iterations(dec.POLL, self.use_graph, klen_bound=kb, live_rows=nlive)      # ... are read while the next window runs
             fsm = dec.poll_result()
+            kb = int(fsm[:, 0].max()) + 3 * dec.POLL
+            nlive = sum(1 for b_ in range(B) if slot_attempt[b_] >= 0 and not fsm[b_, 5]) + 1
             for b in range(B):
                 a = slot_attempt[b]
                 if a < 0 or not fsm[b, 5]:
@@ -567,7 +618,7 @@ class BatchedGenerator:
         try:
             dec.state.check()
         except CommuHipError:
-            dec.state.tail_ok, dec.graph = False, None          # later requests on this decoder: per-Linear launches
+            dec.state.tail_ok, dec.graph, dec.graph_long = False, None, None          # later requests on this decoder: per-Linear launches
             dec.state.t_err.zero_()
             raise
         return out, started

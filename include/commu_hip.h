@@ -383,6 +383,14 @@ int commu_decode_attn(const void* qkv, int ld_qkv, void* kcache, void* vcache, c
                       int ld_rd, const float* r_w_bias, const float* r_r_bias, const int* klen,
                       const unsigned char* active, void* out, int ld_o, int B, int H, int DH, int Lmax,
                       float scale, int append, hipStream_t stream);
+/* The same with the keys of a (sequence, head) pair split over up to nsplit (<= 16) workgroups of >= 512 keys each -- for
+ * long memories with few live sequences, where one workgroup per pair streams its ~1 MB alone.  split_ws: B * H * nsplit *
+ * (DH + 2) floats of scratch; split_cnt: B * H words, ZERO before the first call (the kernel leaves them zero).  Pairs
+ * with at most 512 keys take the unsplit path inside the same launch. */
+int commu_decode_attn_split(const void* qkv, int ld_qkv, void* kcache, void* vcache, const void* rd, int ld_rd,
+                            const float* r_w_bias, const float* r_r_bias, const int* klen, const unsigned char* active,
+                            void* out, int ld_o, int B, int H, int DH, int Lmax, float scale, int append, int nsplit,
+                            float* split_ws, unsigned* split_cnt, hipStream_t stream);
 /* klen[b] += advance[b]  (a step whose memory the reference discards does not advance: quirk Q3) */
 int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lmax, hipStream_t stream);
 /* Everything of a decode-step layer that follows its attention, as ONE launch (csrc/decode_tail.hip):

@@ -431,6 +431,49 @@ def test_cached_decode_at_long_memory_vs_oracle(shape):
     assert checked >= len(gaps) // 2
 
 
+@pytest.mark.parametrize("loaded", [False, True])
+def test_split_key_decode_attention_matches_the_unsplit_kernel(loaded):
+    """commu_decode_attn_split (the keys of a (sequence, head) pair over up to 8 workgroups, the last arriver combines the
+    partial (max, sum, P.V) records inside the launch) against commu_decode_attn on the same caches: ragged memories from 3
+    to 4100 keys (pairs with <= 512 keys take the unsplit path inside the split launch), inactive sequences, repeated
+    launches (the counters must come back to zero), and -- `loaded` -- a second stream keeping the GPU busy so that the
+    workgroups of a pair start unevenly (a stale or missing record would be an O(1) error)."""
+    from commu_amd._lib import call
+    from commu_amd.ops import _p, _s
+    B, H, DH, Lmax = 12, 8, 64, 4200
+    g = torch.Generator().manual_seed(23)
+    qkv = (torch.randn(B, 3 * H * DH, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    kc = (torch.randn(B, H, Lmax, DH, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    vc = (torch.randn(B, H, Lmax, DH, generator=g)).to(torch.bfloat16).to(DEV)
+    rd = (torch.randn(Lmax, H * DH, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    u, vb = (torch.randn(H * DH, generator=g) * 0.3).to(DEV), (torch.randn(H * DH, generator=g) * 0.3).to(DEV)
+    klen = torch.tensor([3, 511, 512, 513, 1000, 1024, 1500, 2047, 3000, 4100, 777, 4199 - 1], dtype=torch.int32, device=DEV)
+    active = torch.ones(B, dtype=torch.uint8, device=DEV)
+    active[10] = 0
+    ws = torch.empty(B * H * 16 * (DH + 2), device=DEV, dtype=torch.float32).fill_(float("nan"))
+    cnt = torch.zeros(B * H, device=DEV, dtype=torch.int32)
+    ref = torch.zeros(B, H * DH, device=DEV, dtype=torch.bfloat16)
+    call("commu_decode_attn", _p(qkv), qkv.stride(0), _p(kc), _p(vc), _p(rd), rd.stride(0), _p(u), _p(vb), _p(klen),
+         _p(active), _p(ref), ref.stride(0), B, H, DH, Lmax, 0.125, 0, _s())
+    side = torch.cuda.Stream()
+    a_ = torch.randn(4096, 4096, device=DEV)
+    for nsplit in (8, 3, 16):
+        for rep in range(4):
+            if loaded:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        a_ @ a_
+            out = torch.zeros(B, H * DH, device=DEV, dtype=torch.bfloat16)
+            call("commu_decode_attn_split", _p(qkv), qkv.stride(0), _p(kc), _p(vc), _p(rd), rd.stride(0), _p(u), _p(vb),
+                 _p(klen), _p(active), _p(out), out.stride(0), B, H, DH, Lmax, 0.125, 0, nsplit, _p(ws), _p(cnt), _s())
+            torch.cuda.synchronize()
+            assert int(cnt.abs().sum()) == 0, (nsplit, rep)
+            d = (out.float() - ref.float()).abs().max()
+            assert float(d) < 2e-2 * float(ref.float().abs().max()), (nsplit, rep, float(d))
+            assert float(out[10].float().abs().max()) == 0          # the inactive sequence is not touched
+
+
 @pytest.mark.parametrize("B,loaded,shape", [(64, False, (6, 8, 512, 1024)), (64, True, (6, 8, 512, 1024)),
                                             (37, False, (6, 8, 512, 1024)), (3, True, (6, 8, 512, 1024)),
                                             (64, True, (6, 10, 500, 1000)), (5, False, (6, 10, 500, 1000))])
