@@ -171,6 +171,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             lds_dma16(srdK, off, ldsw + (unsigned)(OFF_K + (t & 1) * TILEB));
             lds_dma16(srdV, off, ldsw + (unsigned)(OFF_V + (t % 3) * TILEB));
         };
+        // the query rows and biases are requested BEFORE the tile DMAs: loads return in order, so their conversion below
+        // runs while the 64 KB of tiles are still in flight instead of behind them
+        bf16x8 qraw[4];
+        f32x4 ubias[4][2], vbias[4][2];
+        {
+            const int iq = min(iw + ii, T - 1);
+            const bf16* qp = a.q + ((size_t)iq * B + b) * a.ld_qkv + h * 64;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qraw[ks] = ld_bf16x8(qp + 16 * ks + 8 * half);
+                const int f0 = h * 64 + 16 * ks + 8 * half;       // (r_w_bias / r_r_bias rows of 64 floats: 32-byte pieces)
+                ubias[ks][0] = *(const f32x4*)(a.u + f0); ubias[ks][1] = *(const f32x4*)(a.u + f0 + 4);
+                vbias[ks][0] = *(const f32x4*)(a.vb + f0); vbias[ks][1] = *(const f32x4*)(a.vb + f0 + 4);
+            }
+        }
+        asm volatile("" ::: "memory");          // (keep the requests above the DMA issue)
 #pragma unroll
         for (int c = -1; c <= 4; ++c) stage_rd(c);
         stage_kv(0);
@@ -178,14 +194,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bf16x8 qu[4], qv[4];
         {
             const int irow = iw + ii;
-            const int iq = min(irow, T - 1);
-            const bf16* qp = a.q + ((size_t)iq * B + b) * a.ld_qkv + h * 64;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 raw = ld_bf16x8(qp + 16 * ks + 8 * half);
-                const int f0 = h * 64 + 16 * ks + 8 * half;       // (r_w_bias / r_r_bias rows of 64 floats: 32-byte pieces)
-                const f32x4 u0 = *(const f32x4*)(a.u + f0), u1 = *(const f32x4*)(a.u + f0 + 4);
-                const f32x4 v0 = *(const f32x4*)(a.vb + f0), v1 = *(const f32x4*)(a.vb + f0 + 4);
+                const bf16x8 raw = qraw[ks];
+                const f32x4 u0 = ubias[ks][0], u1 = ubias[ks][1], v0 = vbias[ks][0], v1 = vbias[ks][1];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float x = bf2f(raw[e]);
