@@ -349,13 +349,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define SB() __builtin_amdgcn_sched_barrier(0)
             SB();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (h1) Sn = mfma32(kf[ks], qu[ks], Sn);
+            for (int ks = 0; ks < 4; ++ks) {          // (arithmetic first: the first slices run while the operand reads land)
                 sm(2 * ks);
+                if (h1) Sn = mfma32(kf[ks], qu[ks], Sn);
                 if (ks == 1) vread(0);
                 SB();
-                if (h2) acc = mfma32(rf[ks], qv[ks], acc);
                 sm(2 * ks + 1);
+                if (h2) acc = mfma32(rf[ks], qv[ks], acc);
                 if (ks == 1) vread(1);
                 SB();
             }

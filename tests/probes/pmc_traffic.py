@@ -8,7 +8,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-KERNELS = {"relattn_fwd2_kernel": "commu_relattn_fwd", "relattn_fwd_kernel": "commu_relattn_fwd",
+KERNELS = {"relattn_fwd2_kernel": "commu_relattn_fwd", "relattn_fwd3_kernel": "commu_relattn_fwd", "relattn_fwd_kernel": "commu_relattn_fwd",
            "relattn_bwd_q_kernel": "commu_relattn_bwd_q", "relattn_bwd_kv2_kernel": "commu_relattn_bwd_kv",
            "relattn_bwd_kv_kernel": "commu_relattn_bwd_kv"}
 
