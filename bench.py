@@ -336,6 +336,15 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     tokens_per_step = sum(b[3] for b in batches) // len(batches)
 
     step_log = [] if os.environ.get("BENCH_STEP_LOG") else None          # (diagnostics: host time of every step() call)
+    gc_log = []
+    if step_log is not None:          # ... and every collection of the Python garbage collector that falls into one
+        import gc
+        def _gc_cb(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((len(step_log), info["generation"], round(1e3 * (time.perf_counter() - _t[0]), 2)))
+        gc.callbacks.append(_gc_cb)
 
     def run(nsteps, base, sample_events=False):
         for i in range(nsteps):
@@ -378,8 +387,9 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     if step_log is not None:
         ms = torch.cuda.memory_stats()
         print(f"[step log] {args.layers}x{args.d_model} T{args.tgt_len} M{args.mem_len} reset {reset_prob}: elapsed {elapsed:.3f} s; "
-              f"host ms per step() {step_log}; reserved {ms['reserved_bytes.all.current'] >> 20} MiB, segments "
+              f"host ms per step() {step_log}; gc (step, generation, ms) {[g for g in gc_log if g[2] >= 1.0]}; reserved {ms['reserved_bytes.all.current'] >> 20} MiB, segments "
               f"{ms['segment.all.allocated']}, retries {ms['num_alloc_retries']}", file=sys.stderr, flush=True)
+        gc.callbacks.remove(_gc_cb)
     prof = _lib.profile_stop()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -719,6 +719,7 @@ class MemTransformerLM(nn.Module):
         # launch at the end of the pass; only the slab passes over the large bf16 operands are issued where they arise
         # (not under an overlapped gradient exchange: a layer's slice must be final when its hook fires)
         cgrp = ops.ColsumGroup() if getattr(self, "grad_ready_hook", None) is None else None
+        keep.append(cgrp)          # its sources live until the streams are joined at the end of the pass
         defer_light(lambda: ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)), group=cgrp))
         gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
         wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))

@@ -11,6 +11,7 @@ Differences that do not change the arithmetic:
 """
 from __future__ import annotations
 
+import gc
 from typing import List, Optional
 
 import torch
@@ -63,7 +64,7 @@ class Trainer:
 
     MERGE_MAX_ROWS = 65536          # tokens (T x B) up to which the micro-batches of a step are run as ONE pass
 
-    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0, graph=False, merge_chunks=None):
+    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0, graph=False, merge_chunks=None, settle_heap=True):
         """merge_chunks: the reference splits a batch into `batch_chunk` micro-batches to fit its GPU's memory
         (train.py:113-155); each contributes mean(loss over ITS non-pad targets) / batch_chunk.  With 288 GB of HBM the
         columns of all micro-batches go through ONE forward / backward whose loss weights every token by
@@ -72,7 +73,13 @@ class Trainer:
         MERGE_MAX_ROWS tokens; False: the reference's loop.
         graph=True: once the step's shapes are steady (XL memory at its full length) the device work of a step is
         captured in two hipGraphs -- [all micro-batches forward + backward] and [clip + Adam + weight shadows] -- and
-        replayed; the gradient exchange of a multi-GPU job runs between the two replays.  See _graph_step."""
+        replayed; the gradient exchange of a multi-GPU job runs between the two replays.  See _graph_step.
+        settle_heap: after the first step (model, optimiser state, module tables all exist) the Python heap is collected
+        once and moved to the collector's permanent generation (gc.freeze): a full collection of a process with torch
+        loaded walks ~1e6 objects, 70-80 ms on the MI355X host -- fourteen steps' worth at 8 sequences per GPU -- and the
+        step's own short-lived containers trigger one every few dozen steps otherwise (profiles/r04_b8_gc.txt)."""
+        self.settle_heap = bool(settle_heap)
+        self._heap_settled = False
         self.model, self.cfg, self.num_gpus, self.reducer, self.pad_id = model, cfg, num_gpus, reducer, pad_id
         self.graph_mode = bool(graph)
         self.merge_chunks = merge_chunks
@@ -148,7 +155,14 @@ class Trainer:
         self.scheduler.step()
         self.log_grad_norm += grad_norm
         self.log_token_num += int(batch_token_num)
+        if self.settle_heap and not self._heap_settled:
+            self._settle_heap()
         return total
+
+    def _settle_heap(self):
+        gc.collect()
+        gc.freeze()
+        self._heap_settled = True
 
     def _decide_groups(self, data):
         """Fold the step's micro-batches into one pass?  Decided once, at the first step (the XL memories are kept per
@@ -290,6 +304,8 @@ class Trainer:
             # hand the live memories to the graph: from now on they live in its static buffers (the list is the
             # trainer's own: an eager step may rebind its entries without touching the graph's)
             self.mems = list(self._graph_state["mems"])
+            if self.settle_heap:
+                self._settle_heap()                           # the captured graphs' host objects are long-lived too
         st = self._graph_state
         fl = model._flat
         if fl.get("shadow_ready") is not None:                # an EAGER step ran since the last replay: its transposed
