@@ -45,7 +45,8 @@ class ColsumTask(C.Structure):
 
 
 class TnProblem(C.Structure):
-    _fields_ = [("A", c_p), ("B", c_p), ("lda", c_i), ("ldb", c_i), ("N", c_i), ("K", c_i), ("out_off", C.c_longlong)]
+    _fields_ = [("A", c_p), ("B", c_p), ("lda", c_i), ("ldb", c_i), ("N", c_i), ("K", c_i), ("out_off", C.c_longlong),
+                ("colsum_off", C.c_longlong)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPE); stream is always the last c_void_p

@@ -644,8 +644,9 @@ class MemTransformerLM(nn.Module):
         # problems the grouped kernel does not take (small shapes) fall back to the per-GEMM path.
         pending = []
 
-        def wgrad(dY, Xa, gW, rows=None, crop=None):
-            pending.append((dY, Xa, gW, rows, crop))
+        def wgrad(dY, Xa, gW, rows=None, crop=None, colsum=None):
+            # colsum = (fp32 vector, n): vector[:n] += column sums of dY[:, :n] (a bias gradient), from the same launch
+            pending.append((dY, Xa, gW, rows, crop, colsum))
 
         def flush_wgrads():
             if not pending:
@@ -720,9 +721,9 @@ class MemTransformerLM(nn.Module):
         # (not under an overlapped gradient exchange: a layer's slice must be final when its hook fires)
         cgrp = ops.ColsumGroup() if getattr(self, "grad_ready_hook", None) is None else None
         keep.append(cgrp)          # its sources live until the streams are joined at the end of the pass
-        defer_light(lambda: ops.colsum(dlogits[:, :V], gv("crit.out_layers.0.bias", (V,)), group=cgrp))
         gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
-        wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"))
+        # (the output bias gradient = column sums of dlogits: left in the slabs by the weight-gradient launch)
+        wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"), colsum=(gv("crit.out_layers.0.bias", (V,)), V))
         p, patt = sv.p, sv.patt
         inv_keep = 1.0 / (1.0 - p)
 
@@ -786,9 +787,9 @@ class MemTransformerLM(nn.Module):
                 dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_bits=hb, mask_scale=inv_keep)
             else:
                 dhid = ops.gemm_nt(dz2m, sh[f"w2_t{i}"], relu_mask=sv.hid[i], mask_scale=inv_keep)
-            wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"))
-            defer_light(lambda dhid=dhid, pre=pre: ops.colsum(dhid[:, :DIt], gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)),
-                                                             group=cgrp))
+            # (the bias gradient = column sums of dhid comes out of the weight-gradient launch: no pass of its own)
+            wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"),
+                  colsum=(gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)), DIt))
             da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
@@ -818,7 +819,7 @@ class MemTransformerLM(nn.Module):
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
                             scratch=scr[i & 1], defer=(defer_last if last else defer) if side is not None else None,
-                            colsum_group=cgrp)
+                            colsum_group=cgrp, dq_colsum=False)
             gWr = gv(pre + "dec_attn.r_net.weight", (HDt, Dt))
             if side is None:
                 self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"))
@@ -829,7 +830,8 @@ class MemTransformerLM(nn.Module):
                 scr_free[i & 1] = torch.cuda.Event()
                 scr_free[i & 1].record(side)
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
-            wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"))
+            # (d r_r_bias's colsum(dq) term = the first H*DH column sums of dqkv: from the weight-gradient launch)
+            wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"), colsum=(gvb, HD))
             if M > 0:
                 wgrad(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
             flush_wgrads()
@@ -880,11 +882,14 @@ class MemTransformerLM(nn.Module):
         """items = [(dY, X, gW, rows, crop), ...] with a common token count: gW (+)= dY^T X for each, one grouped
         launch + one reduce per problem; falls back to _tn_acc when the grouped kernel does not take the shapes."""
         fl = self._flat
-        arr, Mtok, offs, total = ops.tn_group([(it[0], it[1]) for it in items])
-        ns = ops.tn_group_slices(arr, Mtok) if len(items) <= 8 else 0
+        ncs = sum(1 for it in items if it[5] is not None)
+        arr, Mtok, offs, total, cs_offs = ops.tn_group([(it[0], it[1]) for it in items], colsum=[it[5] is not None for it in items])
+        ns = ops.tn_group_slices(arr, Mtok) if len(items) + ncs <= 8 else 0          # (one reduce launch: <= 8 destinations)
         if ns <= 0:
-            for dY, Xa, gW, rows, crop in items:
+            for dY, Xa, gW, rows, crop, cs in items:
                 self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
+                if cs is not None:
+                    ops.colsum(dY[:, :cs[1]], cs[0])
             return
         need = ns * total
         if fl.get("slabs") is None or fl["slabs"].numel() < need:
@@ -892,8 +897,10 @@ class MemTransformerLM(nn.Module):
         slabs = fl["slabs"]
         ops.gemm_tn_grouped(arr, Mtok, slabs, total, ns)
         red = []
-        for (dY, Xa, gW, rows, crop), off in zip(items, offs):
+        for (dY, Xa, gW, rows, crop, cs), off, cso in zip(items, offs, cs_offs):
             N, Kc = dY.shape[1], Xa.shape[1]
+            if cs is not None:
+                red.append((cs[0], cso, (1, 1, 1, 1, cs[1], N)))
             if crop is not None:
                 rg, rt, rp, cg, ct, cp = crop
                 assert rg * rp == N and cg * cp == Kc, (crop, N, Kc)

@@ -269,9 +269,11 @@ def gemm_tn_raw(A, B, slabs, nslices, mode=None):
     return slabs
 
 
-def tn_group(pairs):
+def tn_group(pairs, colsum=None):
     """ctypes problem array for a grouped weight-gradient launch: pairs = [(dY [M,N], X [M,K]), ...] (bf16, shared M).
-    Returns (array, M, offsets, total) with offsets[i] = element offset of problem i's [N, K] block inside a slab."""
+    Returns (array, M, offsets, total) with offsets[i] = element offset of problem i's [N, K] block inside a slab.
+    colsum: per problem, whether the launch also leaves the column sums of dY (the Linear's bias gradient) in the slabs;
+    then a fifth value, the slab offset of each problem's [N] vector (None where not asked), is returned."""
     arr = (_lib.TnProblem * len(pairs))()
     M = pairs[0][0].shape[0]
     offs, total = [], 0
@@ -281,9 +283,20 @@ def tn_group(pairs):
         arr[i].lda, arr[i].ldb = _rowmajor2d(A, "A"), _rowmajor2d(B, "B")
         arr[i].N, arr[i].K = A.shape[1], B.shape[1]
         arr[i].out_off = total
+        arr[i].colsum_off = -1
         offs.append(total)
         total += A.shape[1] * B.shape[1]
-    return arr, M, offs, total
+    if colsum is None:
+        return arr, M, offs, total
+    cs = []
+    for i, want in enumerate(colsum):
+        if want:
+            arr[i].colsum_off = total
+            cs.append(total)
+            total += round_up(pairs[i][0].shape[1], 4)
+        else:
+            cs.append(None)
+    return arr, M, offs, total, cs
 
 
 def tn_group_slices(arr, M):
@@ -709,9 +722,11 @@ NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead 
 
 
 def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, o, dout, lse, qs, dq, dk, dv,
-                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None, defer=None, colsum_group=None):
+                drd, du, dvb, drop_p=0.0, drop_seed=0, scale=None, scratch=None, defer=None, colsum_group=None,
+                dq_colsum=True):
     """Backward of relattn_fwd.  dq/dk/dv: bf16 2-D views (row stride ld_dqkv) written in place;
-    drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into."""
+    drd: fp32 [K, H*DH] (overwritten); du, dvb: fp32 [H*DH] accumulated into.  dq_colsum=False: the caller adds the
+    colsum(dq) term of dvb itself (the model takes it from the qkv weight-gradient launch)."""
     dev = q.device
     K = T + M
     HD = H * DH
@@ -799,7 +814,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
             drd_reduce()
         else:
             defer(drd_reduce)
-        _bias_grads(dq, du_part, du, dvb, HD, dev, defer, colsum_group)
+        _bias_grads(dq if dq_colsum else None, du_part, du, dvb, HD, dev, defer, colsum_group)
         return delta
     # BD part of dq and dRd: two GEMMs per head over dS-by-distance, batched over the heads
     rdt = transpose_heads(rd, K, 1, H, DH, ld_dsk)                   # [1, H, DH, ld_dsk]
@@ -822,7 +837,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         drd_part()
     else:
         defer(drd_part)
-    _bias_grads(dq, du_part, du, dvb, HD, dev, defer, colsum_group)
+    _bias_grads(dq if dq_colsum else None, du_part, du, dvb, HD, dev, defer, colsum_group)
     return delta
 
 
@@ -834,7 +849,8 @@ def _bias_grads(dq, du_part, du, dvb, HD, dev, defer, group=None):
         if defer is not None:          # local scratch outlives the caller on the deferring stream
             du_part.record_stream(torch.cuda.current_stream())
         colsum(du_part, du, group=group)
-        colsum(dq, dvb, group=group)
+        if dq is not None:
+            colsum(dq, dvb, group=group)
         colsum(du_part, dvb, alpha=-1.0, group=group)
     if defer is None:
         bias_part()

@@ -948,6 +948,7 @@ static bool tn_group_plan(const commu_tn_problem* probs, int nprob, int M, Tn8Ar
         Tn8Prob& t = out->p[i];
         t.A = (const bf16*)q.A; t.B = (const bf16*)q.B; t.lda = q.lda; t.ldb = q.ldb; t.N = q.N; t.Kc = q.K;
         t.tiles_n = (q.N + 255) / 256; t.tiles_k = (q.K + 255) / 256; t.tile0 = tiles; t.out_off = q.out_off;
+        t.colsum_off = q.colsum_off;
         tiles += t.tiles_n * t.tiles_k;
     }
     out->nprob = nprob; out->M = M; out->total_tiles = tiles;

@@ -31,6 +31,7 @@ struct Tn8Prob {
     int lda, ldb, N, Kc;
     int tiles_n, tiles_k, tile0;          // 256 x 256 output tiles; first tile id of this problem
     long long out_off;                    // element offset of this problem's [N, Kc] block inside a slab
+    long long colsum_off;                 // >= 0: column sums of A ([N] floats) at this slab offset
 };
 struct Tn8Args {
     Tn8Prob p[8];

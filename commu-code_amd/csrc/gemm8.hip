@@ -578,12 +578,12 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
     const bf16* Ap = a.p[0].A;
     const bf16* Bp = a.p[0].B;
     int lda = a.p[0].lda, ldb = a.p[0].ldb, N = a.p[0].N, Kc = a.p[0].Kc, tiles_k = a.p[0].tiles_k, tile0 = 0;
-    long long out_off = a.p[0].out_off;
+    long long out_off = a.p[0].out_off, colsum_off = a.p[0].colsum_off;
 #pragma unroll
     for (int i = 1; i < 8; ++i)
         if (pi == i) {
             Ap = a.p[i].A; Bp = a.p[i].B; lda = a.p[i].lda; ldb = a.p[i].ldb; N = a.p[i].N; Kc = a.p[i].Kc;
-            tiles_k = a.p[i].tiles_k; tile0 = a.p[i].tile0; out_off = a.p[i].out_off;
+            tiles_k = a.p[i].tiles_k; tile0 = a.p[i].tile0; out_off = a.p[i].out_off; colsum_off = a.p[i].colsum_off;
         }
     const int tl = tile - tile0;
     const int n0 = (tl / tiles_k) * 256, k0 = (tl % tiles_k) * 256;
@@ -645,6 +645,21 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // column sums of dY (a bias gradient) ride along in the workgroups of the first K-tile column: wave (wr, wc) multiplies
+    // its dY fragments of column block wc by a fragment of ones -- 2 MFMAs beside the 32 of phases 1 and 3
+    const bool csum = colsum_off >= 0 && k0 == 0;
+    f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    typedef __attribute__((ext_vector_type(4))) unsigned tn_u32x4;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (tn_u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+#define TN8_COLSUM(H)                                                                                                \
+    if (csum) {                                                                                                      \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                             \
+            if (wc == mi) {                                                                                          \
+                accb[H] = mfma16(ones, xf[mi][0], accb[H]);                                                          \
+                accb[H] = mfma16(ones, xf[mi][1], accb[H]);                                                          \
+            }                                                                                                        \
+    }
+
     if (nsteps > 0) {
         stage(Q_XLO, 0, 0);
         stage(Q_WHI, 0, 0);
@@ -687,6 +702,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16(wf[ni][kk], xf[mi][kk], acc[ni][mi]);
+        TN8_COLSUM(0)
         __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---- phase 2: (Xlo, Whi)
@@ -724,6 +740,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[2 + ni][4 + mi] = mfma16(wf[ni][kk], xf[mi][kk], acc[2 + ni][4 + mi]);
+        TN8_COLSUM(1)
         __builtin_amdgcn_s_setprio(0);
         G8_BAR();
         // ---- phase 4: (Xhi, Wlo)
@@ -764,6 +781,15 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
             if (k < Kc) *(f32x4*)(out + (size_t)n * Kc + k) = acc[wb][xb];
         }
     }
+    if (csum && g == 0) {          // every row of the ones product is the column sum: row 0 (lanes g == 0, register 0)
+        float* cs = a.slabs + (size_t)slice * a.slab_stride + colsum_off;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int n = n0 + 128 * hh + 64 * wr + 16 * wc + r16;
+            if (n < N) cs[n] = accb[hh][0];
+        }
+    }
+#undef TN8_COLSUM
 }
 
 }  // namespace

@@ -86,6 +86,10 @@ typedef struct commu_tn_problem {
     const void* B;      /* bf16 [M][ldb]  (layer input) */
     int lda, ldb, N, K;
     long long out_off;  /* element offset of this problem's [N, K] block inside a slab */
+    long long colsum_off; /* >= 0: the slice's column sums of A (sum_m A[m, n]: the bias gradient of the Linear whose dY this
+                           * is, commu/model/model.py:163-169) go to slabs[s * slab_stride + colsum_off + n], n < N -- one
+                           * extra MFMA per 64 tokens in the workgroups of the first K tile column, instead of a separate
+                           * pass over dY; < 0: none */
 } commu_tn_problem;
 /* number of token slices that fills the 256 CUs for this group (0: a problem is not eligible) */
 int commu_gemm_tn_grouped_slices(const commu_tn_problem* probs, int nprob, int M);

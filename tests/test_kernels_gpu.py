@@ -250,6 +250,34 @@ def test_gemm_tn_grouped_eight_phase(M):
             out = torch.zeros(N, K, device=DEV)
             o.reduce_slabs(out, slabs[off:], N * K, nslices, total, False)
             assert relerr(out, ref) < F32_TOL, (N, K, nslices)
+    # the same launch with the column sums of dY (bias gradients) asked for on three of the five problems -- a multi-tile N,
+    # a K of two tile columns (only the first computes them) and the partial tile -- and every product unchanged
+    want = [True, False, False, True, True]
+    arr, Mm, offs, total, cs = o.tn_group(pairs, colsum=want)
+    assert [c is not None for c in cs] == want
+    for nslices in sorted({ns, 3}):
+        slabs = torch.full((nslices * total,), float("nan"), device=DEV)
+        o.gemm_tn_grouped(arr, Mm, slabs, total, nslices)
+        items = []
+        outs = []
+        for (N, K), off, cso, (A, _) in zip(shapes, offs, cs, pairs):
+            out = torch.zeros(N, K, device=DEV)
+            items.append((out, off, (1, N, N, 1, K, K)))
+            outs.append(out)
+            if cso is not None:
+                ncrop = N - 8                         # a cropped destination (zero-padded models), accumulated into
+                vec = torch.full((ncrop,), 2.0, device=DEV)
+                items.append((vec, cso, (1, 1, 1, 1, ncrop, N)))
+                outs.append((vec, A.float().sum(0)[:ncrop] + 2.0))
+        o.reduce_slabs_group(items, slabs, nslices, total, True)
+        k = 0
+        for (N, K), ref, cso in zip(shapes, refs, cs):
+            assert relerr(outs[k], ref) < F32_TOL, (N, K, nslices)
+            k += 1
+            if cso is not None:
+                vec, vref = outs[k]
+                assert relerr(vec, vref) < F32_TOL, ("colsum", N, nslices)
+                k += 1
 
 
 def test_gemm_tn_grouped_asymmetric():
