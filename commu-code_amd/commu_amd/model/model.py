@@ -648,14 +648,24 @@ class MemTransformerLM(nn.Module):
             # colsum = (fp32 vector, n): vector[:n] += column sums of dY[:, :n] (a bias gradient), from the same launch
             pending.append((dY, Xa, gW, rows, crop, colsum))
 
+        # Work deferred to the first side stream is collected and handed over at the next flush_wgrads() with ONE event: an
+        # event record costs the main queue 6-8 us (the trace shows the gap in front of the next kernel), and a layer used to
+        # record one per deferred call -- four between the band pass and the next dX GEMM.  Nothing is launched on the main
+        # stream between a defer() and the flush that follows it, so the later hand-over reads the same data.
+        side_fns = []
+
         def flush_wgrads():
-            if not pending:
+            if not pending and not side_fns:
                 return
             batch = list(pending)
             pending.clear()
+            fns = list(side_fns)
+            side_fns.clear()
             keep.extend(t for it in batch for t in it[:2])
 
             def run():
+                for fn in fns:
+                    fn()
                 groups = {}
                 for it in batch:
                     groups.setdefault(it[0].shape[0], []).append(it)
@@ -692,14 +702,10 @@ class MemTransformerLM(nn.Module):
                 side2.wait_event(ev)
                 fn()
 
-        def defer(fn):          # fn's kernels go to the side stream, ordered after what main has enqueued so far
+        def defer(fn):          # fn's kernels go to the side stream at the next flush_wgrads() (see side_fns)
             if side is None:
                 return fn()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                fn()
+            side_fns.append(fn)
         # dS-by-distance scratch: two buffers alternate between layers, so that the deferred dRd GEMM of layer i may
         # still read its buffer while layer i-1's attention backward fills the other one
         scr = fl.setdefault("attn_scratch", [{}, {}])
@@ -721,6 +727,8 @@ class MemTransformerLM(nn.Module):
         # (not under an overlapped gradient exchange: a layer's slice must be final when its hook fires)
         cgrp = ops.ColsumGroup() if getattr(self, "grad_ready_hook", None) is None else None
         keep.append(cgrp)          # its sources live until the streams are joined at the end of the pass
+        # (a reduction that only joins the group launches nothing: no stream hand-over, no event)
+        light = (lambda fn: fn()) if cgrp is not None else defer_light
         gE = gv("word_emb.emb_layers.0.weight", (V, Dt))
         # (the output bias gradient = column sums of dlogits: left in the slabs by the weight-gradient launch)
         wgrad(dlogits, sv.hL, gE, rows=V, crop=spec("Egrad"), colsum=(gv("crit.out_layers.0.bias", (V,)), V))
@@ -776,7 +784,7 @@ class MemTransformerLM(nn.Module):
             if dz2m is None:
                 dz2m = dz2
             keep.append(part)
-            defer_light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
+            light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
                 part, gv(pre + "pos_ff.layer_norm.weight", (Dt,)), gv(pre + "pos_ff.layer_norm.bias", (Dt,)),
                 gv(pre + "pos_ff.CoreNet.3.bias", (Dt,)), group=cgrp))
             wgrad(dz2m, sv.hid[i], gv(pre + "pos_ff.CoreNet.3.weight", (Dt, DIt)), crop=spec("w2"))
@@ -797,7 +805,7 @@ class MemTransformerLM(nn.Module):
             if dz1m is None:
                 dz1m = dz1
             keep.append(part)
-            defer_light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
+            light(lambda part=part, pre=pre: ops.layernorm_bwd_reduce(
                 part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)), gv(pre + "dec_attn.layer_norm.bias", (Dt,)), group=cgrp))
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             last = i == 0
@@ -827,8 +835,13 @@ class MemTransformerLM(nn.Module):
                 keep.append(drd)
                 (defer_last if last else defer)(lambda drd=drd, gWr=gWr, ws="slabs2" if last else "slabs": self._tn_acc(
                     ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"), ws=ws))
-                scr_free[i & 1] = torch.cuda.Event()
-                scr_free[i & 1].record(side)
+                def mark_free(i=i):          # (after the deferred work above: it is enqueued at the flush below)
+                    scr_free[i & 1] = torch.cuda.Event()
+                    scr_free[i & 1].record(side)
+                if last:
+                    mark_free()
+                else:
+                    defer(mark_free)
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
             # (d r_r_bias's colsum(dq) term = the first H*DH column sums of dqkv: from the weight-gradient launch)
             wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"), colsum=(gvb, HD))
@@ -867,9 +880,11 @@ class MemTransformerLM(nn.Module):
             if side is not None:      # the grouped final column sums: after every slab pass on either side stream
                 with torch.cuda.stream(side2):
                     side2.wait_stream(side)
+                    side2.wait_stream(main)          # (sources that joined the group without a hand-over of their own)
                     cgrp.flush()
             else:
                 cgrp.flush()
+        flush_wgrads()
         join()
         if pad:
             gu_t.view(H, DHt).add_(gu.view(H, DH)[:, :DHt])
