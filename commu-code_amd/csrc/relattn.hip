@@ -947,9 +947,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int reg = 0; reg < 4; ++reg) {
                 const float p = __builtin_amdgcn_exp2f(s[c][reg]);          // P * scale / (1-p)
                 float dpe = dp[c][reg];                                       // dP - delta (1-p)
-                if (DROP) dpe = drop_keep16(hw, reg, a.drop_thr, thr_hi) ? dpe : ndl[reg];
+                float ps = p;
+                if (DROP) {
+                    const bool keep = drop_keep16(hw, reg, a.drop_thr, thr_hi);
+                    dpe = keep ? dpe : ndl[reg];
+                    ps = keep ? p : -p;          // the stored probability carries the keep decision in its sign: the
+                }                                // key-stationary kernel does not hash again
                 db[reg] = f2bf(p * dpe);
-                pq[reg] = f2bf(p);
+                pq[reg] = f2bf(ps);
             }
             // the key-stationary kernel re-reads P instead of recomputing it (block of 16 rows x 64 keys, P^T image order)
             if (DH == 64)
@@ -1264,9 +1269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int jslot, h, b;
     tile_coords(NH, a.H, B, jslot, h, b);
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
-    DropLane dl_;
-    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
-    const unsigned thr_hi = a.drop_thr << 16;
+    // (dropout: the keep decisions arrive in the sign of the stored probabilities -- no hash in this kernel)
     // P' = P ln2/(1-p):  dS'' = P' (keep dP - delta (1-p)),  dV = [sum keep P' dO] / ln2   (see relattn_bwd_kv_kernel);
     // stored is P scale/(1-p)
     const float dsc = DROP ? a.drop_scale : 1.f;
@@ -1343,17 +1346,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             f32x4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) dp = mfma16(ld_bf16x8(sdO + 16 * rb * DH + foff[ks]), vf[ks], dp);
-            unsigned hw[2] = {0u, 0u};
-            if (DROP) dl_.words((i0 >> 4) + rb, jw_lo >> 4, hw);
             const f32x4 rs4 = *(const f32x4*)&sRs[16 * rb + 4 * g], dl4 = *(const f32x4*)&sDl[16 * rb + 4 * g];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p = bf2f(pu[rb][reg]) * rs4[reg];          // P' = P ln2 / (1-p)
+                const float x = bf2f(pu[rb][reg]) * rs4[reg];          // +-P' = P ln2 / (1-p), negative: dropped (bwd_q)
+                const float p = DROP ? __builtin_fabsf(x) : x;
                 float pd = p, dpe = dp[reg];
                 if (DROP) {
-                    const bool keep = drop_keep16(hw, reg, a.drop_thr, thr_hi);
-                    pd = keep ? p : 0.f;
-                    dpe = keep ? dpe : 0.f;
+                    pd = __builtin_fmaxf(x, 0.f);
+                    dpe = x > 0.f ? dpe : 0.f;          // (p == 0: either branch gives dS'' = 0)
                 }
                 pb[rb][reg] = f2bf(pd);
                 dsb[rb][reg] = f2bf(p * (dpe - dl4[reg]));
