@@ -1468,8 +1468,21 @@ __global__ void __launch_bounds__(256) mems_update_kernel(const bf16* __restrict
     const uint4* h = reinterpret_cast<const uint4*>(hids + (size_t)l * hid_stride + hid_skip);
     uint4* o = reinterpret_cast<uint4*>(out + (size_t)l * out_stride);
     const size_t nk = keep / 8, n = nk + take / 8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        o[i] = i < nk ? m[i] : h[i - nk];
+    // four independent 16-byte loads in flight per thread (one at a time streamed at 1.5 TB/s: 628 us for the 0.94 GB of the
+    // released default configuration)
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < n; i += 4 * step) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t j = i + u * step;
+            v[u] = j < nk ? m[j] : h[j - nk];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[i + u * step] = v[u];
+    }
+    for (; i < n; i += step) o[i] = i < nk ? m[i] : h[i - nk];
 }
 
 extern "C" int commu_mems_update(const void* hids, size_t hid_stride, size_t hid_skip, size_t take, const void* mems,
@@ -1480,7 +1493,7 @@ extern "C" int commu_mems_update(const void* hids, size_t hid_stride, size_t hid
     if ((keep && !mems) || (take && !hids) || !out) return -22;
     const size_t n = (keep + take) / 8;
     int bx = (int)((n + 255) / 256);
-    if (bx > 2048 / layers + 1) bx = 2048 / layers + 1;
+    if (bx > 4096 / layers + 1) bx = 4096 / layers + 1;
     COMMU_LAUNCH(mems_update_kernel, dim3(bx, layers), dim3(256), 0, stream, (const bf16*)hids, hid_stride, hid_skip, take,
                  (const bf16*)mems, mem_stride, mem_skip, keep, (bf16*)out, out_stride);
     COMMU_LAUNCH_CHECK();
