@@ -93,48 +93,37 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float, version: int = 1):
-    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests).
-    version 1 (relattn.hip DropLane; every kernel of the 16x16-layout family, forward and backward): every 16x16 block
-    (i>>4, j>>4) of a (batch, head) has a 32-bit key from the strong hash (scalar work in the kernels); inside the block a
-    cheap two-round 24-bit multiply hash of (row pair, column) gives one word per two rows: low 16 bits -> even row, high
-    16 bits -> odd row, compared with round(p * 65536).
-    version 2 (relattn3.hip, commu_attn_fwd_generation(3)): 32x32 blocks (i>>5, j>>5) with three scalar keys; one mixed
-    index per (row, key pair) and one 24-bit multiply-add per key -- even and odd key use different constants --, the whole
-    32-bit word against round(p * 65536) << 16."""
+def attn_dropout_keep_mask(seed: int, B: int, H: int, T: int, K: int, p: float, version: int = 3):
+    """The attention kernels' keep mask [B,H,T,K] (reference implementation for tests; relattn.hip DropLane).  One mask for
+    every kernel: each 32x32 block (i>>5, j>>5) of a (batch, head) has a 32-bit key k1 from the strong hash; inside the block
+    one mixed word per 2x2 cell, y = ((i&31)>>1 << 4 | (j&31)>>1) * C1 + k1, y ^= y >> 12, y &= 0xFFFFFF, and one
+    multiply-add per element with the constants of its place in the cell, w = y * CM[i&1][j&1] + k1 * KA[i&1][j&1] +
+    KB[i&1][j&1]; keep = w >= round(p * 65536) << 16.  (`version` is accepted for older call sites and ignored.)"""
     thr = max(1, int(p * 65536.0 + 0.5)) if p > 0 else 0
     out = torch.empty(B, H, T, K, dtype=torch.bool)
     rows = torch.arange(T, dtype=torch.int64)[:, None]
     cols = torch.arange(K, dtype=torch.int64)[None, :]
     M32 = 0xFFFFFFFF
-    if version == 2:
-        blk = ((rows >> 5) << 16) | (cols >> 5)
-        xc = ((((rows & 31) << 4) | ((cols & 31) >> 1)) * 0xD2B74B) & M32
-        odd = (cols & 1).bool().expand(T, K)
-        for b in range(B):
-            for h in range(H):
-                key_bh = int(_mix32(torch.tensor((seed + (b * H + h) * 0x9E3779B1) & M32, dtype=torch.int64)))
-                k1 = _mix32k(blk, key_bh)
-                k2 = (k1 * 0x85EBCA6B + 0x6A09E667) & M32
-                k3 = (k1 * 0xC2B2AE35 + 0xBB67AE85) & M32
-                y = (xc + k1) & M32
-                y = (y ^ (y >> 12)) & 0xFFFFFF
-                w = torch.where(odd, (y * 0x85EBCB + k3) & M32, (y * 0x9E3779 + k2) & M32)
-                out[b, h] = w >= (thr << 16)
-        return out, 1.0 - thr / 65536.0
-    blk = ((rows >> 4) << 16) | (cols >> 4)
-    xc = ((((rows & 15) >> 1) << 4) | (cols & 15)) * 0xD2B74B
+    CM = ((0x9E3779, 0x85EBCB), (0xC2B2AF, 0xB5297B))
+    KA = ((0x85EBCA6B, 0xC2B2AE35), (0x27D4EB2F, 0x165667B1))
+    KB = ((0x6A09E667, 0xBB67AE85), (0x3C6EF372, 0xA54FF53A))
+    blk = ((rows >> 5) << 16) | (cols >> 5)
+    xc = (((((rows & 31) >> 1) << 4) | ((cols & 31) >> 1)) * 0xD2B74B) & M32
+    ri = (rows & 1).expand(T, K)
+    ci = (cols & 1).expand(T, K)
     for b in range(B):
         for h in range(H):
-            key_bh = int(_mix32(torch.tensor((seed + (b * H + h) * 0x9E3779B1) & 0xFFFFFFFF, dtype=torch.int64)))
+            key_bh = int(_mix32(torch.tensor((seed + (b * H + h) * 0x9E3779B1) & M32, dtype=torch.int64)))
             k1 = _mix32k(blk, key_bh)
-            k2 = (k1 * 0x85EBCA6B + 0x6A09E667) & 0xFFFFFFFF
-            y = (xc + k1) & 0xFFFFFFFF
-            y = y ^ (y >> 12)
-            y = ((y & 0xFFFFFF) * 0x9E3779 + k2) & 0xFFFFFFFF
-            y = y ^ (y >> 15)
-            half = (y >> (16 * (rows & 1))) & 0xFFFF
-            out[b, h] = half >= thr
+            y = (xc + k1) & M32
+            y = (y ^ (y >> 12)) & 0xFFFFFF
+            w = torch.zeros(T, K, dtype=torch.int64)
+            for r_ in range(2):
+                for c_ in range(2):
+                    sel = (ri == r_) & (ci == c_)
+                    wv = (y * CM[r_][c_] + ((k1 * KA[r_][c_] + KB[r_][c_]) & M32)) & M32
+                    w = torch.where(sel, wv, w)
+            out[b, h] = w >= (thr << 16)
     return out, 1.0 - thr / 65536.0
 
 

@@ -76,38 +76,56 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* img, int kbase, int r16, i
     return f;
 }
 
-// Attention-probability dropout (K16).  keep(b,h,i,j): every 16x16 block (i>>4, j>>4) of a (batch, head) pair has a
-// 32-bit key from the strong hash -- block coordinates are wave-uniform in all three kernels, so that is SCALAR work
-// -- and inside the block a cheap two-round hash on full-rate 24-bit multiplies of (row pair, column) gives one word
-// per two rows: low 16 bits -> even row, high 16 bits -> odd row, compared with the 16-bit threshold.  (The previous
-// form, one 32-bit lowbias hash per word on the vector unit, cost two quarter-rate v_mul_lo_u32 and ~11 more VALU
-// instructions per word: a quarter of the forward kernel's time.)  Host mirror: ops.attn_dropout_keep_mask.
-constexpr unsigned DROP_C1 = 0xD2B74Bu, DROP_C2 = 0x9E3779u;
+// Attention-probability dropout (K16), ONE mask for every attention kernel (both forward generations, backward).
+// keep(b, h, i, j): every 32x32 block (i >> 5, j >> 5) of a (batch, head) has a 32-bit key k1 from the strong hash -- block
+// coordinates are wave-uniform in all kernels, so that is SCALAR work -- and inside the block a two-round hash on full-rate
+// 24-bit multiplies: one mixed word per 2 x 2 cell,
+//     y = ((i & 31) >> 1 << 4 | (j & 31) >> 1) * C1 + k1;  y ^= y >> 12;  y &= 0xFFFFFF
+// and one multiply-add per element whose constants depend on the element's place in the cell,
+//     w = y * CM[i & 1][j & 1] + (k1 * KA[i & 1][j & 1] + KB[i & 1][j & 1]);     keep = w >= round(p * 65536) << 16.
+// Whichever two elements of a cell a lane holds -- two ROWS of one key in the 16x16 layout (registers 0,1 / 2,3), two KEYS of
+// one query in the transposed 32x32 layout -- share the first round: 2.5 instructions per element in either layout, so the
+// forward of one generation and the backward of the other regenerate the same mask.  (Before: one word per row pair in
+// the 16x16 family and one per key pair in relattn3.hip -- two masks, and the faster forward unusable in training.)
+// Host mirror: ops.attn_dropout_keep_mask.
+constexpr unsigned DROP_C1 = 0xD2B74Bu;
+constexpr unsigned DROP_CM[2][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0xB5297Bu}};
+constexpr unsigned DROP_KA[2][2] = {{0x85EBCA6Bu, 0xC2B2AE35u}, {0x27D4EB2Fu, 0x165667B1u}};
+constexpr unsigned DROP_KB[2][2] = {{0x6A09E667u, 0xBB67AE85u}, {0x3C6EF372u, 0xA54FF53Au}};
 struct DropLane {
-    unsigned xc[2];        // ((row pair 2g+rp) << 4 | column r16) * C1 : the lane's two words of any block (C layout)
+    unsigned xc[2];        // ((2 g + rp) << 4 | r16 >> 1) * C1: the lane's two cells of a 16x16 tile (C layout: rows 4g + reg)
+    unsigned cm[2];        // CM[row parity][this lane's key parity]
+    bool jodd;
     unsigned key_bh;
     __device__ __forceinline__ void init(unsigned seed, int b, int h, int H, int g, int r16) {
         key_bh = mix32(seed + (unsigned)(b * H + h) * 0x9E3779B1u);
-        xc[0] = (unsigned)(((2 * g) << 4) | r16) * DROP_C1;
-        xc[1] = (unsigned)(((2 * g + 1) << 4) | r16) * DROP_C1;
+        xc[0] = (unsigned)(((2 * g) << 4) | (r16 >> 1)) * DROP_C1;
+        xc[1] = (unsigned)(((2 * g + 1) << 4) | (r16 >> 1)) * DROP_C1;
+        jodd = (r16 & 1) != 0;
+        cm[0] = jodd ? DROP_CM[0][1] : DROP_CM[0][0];
+        cm[1] = jodd ? DROP_CM[1][1] : DROP_CM[1][0];
     }
-    // hash words of block (ib, jb) = (i >> 4, j >> 4); both must be wave-uniform
-    __device__ __forceinline__ void words(int ib, int jb, unsigned (&hw)[2]) const {
-        const unsigned k1 = mix32k(((unsigned)ib << 16) | (unsigned)jb, key_bh);
-        const unsigned k2 = k1 * 0x85EBCA6Bu + 0x6A09E667u;
+    // hash words of the lane's four elements (rows 4g + reg) of the 16x16 tile (ib, jb) = (i >> 4, j >> 4); both wave-uniform
+    __device__ __forceinline__ void words(int ib, int jb, unsigned (&hw)[4]) const {
+        const unsigned k1 = mix32k(((unsigned)(ib >> 1) << 16) | (unsigned)(jb >> 1), key_bh);
+        // (the tile's place inside its 32x32 block: + 8 row pairs / + 8 key pairs, folded into the additive key)
+        const unsigned kk = k1 + (unsigned)((((ib & 1) << 3) << 4) | ((jb & 1) << 3)) * DROP_C1;
+        const unsigned ke0 = k1 * DROP_KA[0][0] + DROP_KB[0][0], ko0 = k1 * DROP_KA[0][1] + DROP_KB[0][1];
+        const unsigned ke1 = k1 * DROP_KA[1][0] + DROP_KB[1][0], ko1 = k1 * DROP_KA[1][1] + DROP_KB[1][1];
+        const unsigned kr0 = jodd ? ko0 : ke0, kr1 = jodd ? ko1 : ke1;
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp) {
-            unsigned y = xc[rp] + k1;
+            unsigned y = xc[rp] + kk;
             y ^= y >> 12;
-            y = (y & 0xFFFFFFu) * DROP_C2 + k2;
-            y ^= y >> 15;
-            hw[rp] = y;
+            y &= 0xFFFFFFu;
+            hw[2 * rp] = y * cm[0] + kr0;
+            hw[2 * rp + 1] = y * cm[1] + kr1;
         }
     }
 };
-// reg = row 4g+reg of the block: even rows take the low half of word reg>>1, odd rows the high half
-__device__ __forceinline__ bool drop_keep16(const unsigned (&hw)[2], int reg, unsigned thr, unsigned thr_hi) {
-    return (reg & 1) ? hw[reg >> 1] >= thr_hi : (unsigned short)hw[reg >> 1] >= (unsigned short)thr;
+// reg = row 4g+reg of the tile
+__device__ __forceinline__ bool drop_keep16(const unsigned (&hw)[4], int reg, unsigned /*thr*/, unsigned thr_hi) {
+    return hw[reg] >= thr_hi;
 }
 
 __device__ __forceinline__ float bperm(int addr, float v) {
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_fwd_kernel(const AttnArgs a) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 pb;
-            unsigned hw[2] = {0u, 0u};
+            unsigned hw[4] = {0u, 0u, 0u, 0u};
             if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const f32x2 m01 = {mrow[0], mrow[1]}, m23 = {mrow[2], mrow[3]};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            unsigned hw[2] = {0u, 0u};
+            unsigned hw[4] = {0u, 0u, 0u, 0u};
             if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
             const f32x2 e01 = (f32x2){s[c][0], s[c][1]} - m01, e23 = (f32x2){s[c][2], s[c][3]} - m23;
             f32x2 p01 = {__builtin_amdgcn_exp2f(e01[0]), __builtin_amdgcn_exp2f(e01[1])};
@@ -940,7 +958,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bf16x4 db;
-            unsigned hw[2] = {0u, 0u};
+            unsigned hw[4] = {0u, 0u, 0u, 0u};
             if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
             bf16x4 pq;
 #pragma unroll
@@ -1185,7 +1203,7 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
                 qr0 = mfma16(qvf, ld_bf16x8(r0 + foff[ks]), qr0);
                 qr1 = mfma16(qvf, ld_bf16x8(r1 + foff[ks]), qr1);
             }
-            unsigned hw[2] = {0u, 0u};
+            unsigned hw[4] = {0u, 0u, 0u, 0u};
             if (DROP) dl_.words((i0 >> 4) + rb, jw_lo >> 4, hw);
             const f32x4 lse4 = *(const f32x4*)&sLse[16 * rb + 4 * g], dl4 = *(const f32x4*)&sDl[16 * rb + 4 * g];
             // skewed band term: block select at the SOURCE lane (dest lane s < row  <=>  source lane t < row), one permute
@@ -1507,10 +1525,11 @@ extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse
     // tiles at every shape of this model, so only NW = 4 is instantiated)
     dim3 grid((((d->T + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
-    // d_head 64: third generation (relattn3.hip) unless the pass has attention dropout (commu_attn_fwd_generation)
+    // d_head 64: third generation (relattn3.hip), with or without attention dropout -- every kernel regenerates the same mask
+    // (commu_attn_fwd_generation(2) forces the 16x16 kernel)
     const int fwd_gen = g_fwd_gen;
-    if (d->DH == 64 && (fwd_gen == 3 || (fwd_gen == 0 && !drop))) return launch_relattn_fwd3(a, stream);
-    if (d->DH == 64 && (fwd_gen == 2 || fwd_gen == 0)) {          // second-generation kernel: 128 query rows per workgroup
+    if (d->DH == 64 && (fwd_gen == 3 || fwd_gen == 0)) return launch_relattn_fwd3(a, stream);
+    if (d->DH == 64 && fwd_gen == 2) {          // second-generation kernel: 128 query rows per workgroup
         dim3 grid2((((d->T + 127) / 128 + 1) / 2) * d->H * d->B);
         static const int stag = getenv("COMMU_ATTN_FWD_STAG") ? atoi(getenv("COMMU_ATTN_FWD_STAG")) : 0;
         if (stag == 1) {

@@ -70,11 +70,13 @@ __device__ __forceinline__ int swz3(int R) {
     return ((p & 1) << 2) | (p & 2) | ((p >> 2) & 1);
 }
 
-// attention-probability dropout, second form (pairs along the KEYS: the transposed layout holds 4 consecutive keys of one
-// query per accumulator quad).  Per 32x32 block (i >> 5, j >> 5) of a (batch, head): scalar keys k1, k2, k3 from the
-// strong hash; element (ii, jj): a = ((ii << 4 | jj >> 1) * C1 + k1), a ^= a >> 12, word = (a & 0xFFFFFF) * (jj & 1 ? C3 :
-// C2) + (jj & 1 ? k3 : k2); keep = word >= thr16 << 16.  Host mirror: ops.attn_dropout_keep_mask(version=2).
-constexpr unsigned DROP_C1 = 0xD2B74Bu, DROP_C2 = 0x9E3779u, DROP_C3 = 0x85EBCBu;
+// attention-probability dropout: the mask of relattn.hip (DropLane: one mixed word per 2 x 2 cell of a 32x32 block, one
+// multiply-add per element with the constants of its place in the cell).  Here a lane is one query and an accumulator quad
+// holds 4 consecutive keys: the two keys of a cell share the first round, the query's parity picks the lane's constants.
+constexpr unsigned DROP_C1 = 0xD2B74Bu;
+constexpr unsigned DROP_CM[2][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0xB5297Bu}};
+constexpr unsigned DROP_KA[2][2] = {{0x85EBCA6Bu, 0xC2B2AE35u}, {0x27D4EB2Fu, 0x165667B1u}};
+constexpr unsigned DROP_KB[2][2] = {{0x6A09E667u, 0xBB67AE85u}, {0x3C6EF372u, 0xA54FF53Au}};
 
 template <bool DROP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void relattn_fwd3_kernel(const AttnArgs a) {
@@ -142,7 +144,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 4; ++q) ar[u][q] = rowb + 4 * (60 - ((32 * u + 8 * q + 4 * half - 4 * (ii >> 2)) & 63));
 
     const unsigned key_bh = DROP ? mix32(salted(a.drop_seed) + (unsigned)(b * a.H + h) * 0x9E3779B1u) : 0u;
-    const unsigned xl = (unsigned)((ii << 4) | (2 * half)) * DROP_C1;
+    const unsigned xl = (unsigned)(((ii >> 1) << 4) | (2 * half)) * DROP_C1;
+    const bool iodd = (ii & 1) != 0;
+    const unsigned cme = iodd ? DROP_CM[1][0] : DROP_CM[0][0], cmo = iodd ? DROP_CM[1][1] : DROP_CM[0][1];
     const unsigned thr32 = a.drop_thr << 16;
 
     auto tr8 = [&](int byte_off) {
@@ -311,8 +315,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             unsigned k1 = 0, k2 = 0, k3 = 0;
             if (DROP) {
                 k1 = mix32k(((unsigned)(iw >> 5) << 16) | (unsigned)(2 * jt_lo + n), key_bh);
-                k2 = k1 * 0x85EBCA6Bu + 0x6A09E667u;
-                k3 = k1 * 0xC2B2AE35u + 0xBB67AE85u;
+                // (additive keys of the even / odd key of a cell, for this lane's query parity)
+                k2 = iodd ? k1 * DROP_KA[1][0] + DROP_KB[1][0] : k1 * DROP_KA[0][0] + DROP_KB[0][0];
+                k3 = iodd ? k1 * DROP_KA[1][1] + DROP_KB[1][1] : k1 * DROP_KA[0][1] + DROP_KB[0][1];
             }
             unsigned pw[8];
             auto sm = [&](int k) {                                // keys 2k, 2k+1 of the quad layout: exp, sums, dropout, bf16 pair
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // 4 (k >> 1) + 2 half + 1 - (k & 1), odd key first
                     unsigned y = xl + ((unsigned)(4 * (k >> 1) + 1 - (k & 1)) * DROP_C1 + k1);
                     y ^= y >> 12;
-                    const unsigned w0 = (y & 0xFFFFFFu) * DROP_C2 + k2, w1 = (y & 0xFFFFFFu) * DROP_C3 + k3;
+                    const unsigned w0 = (y & 0xFFFFFFu) * cme + k2, w1 = (y & 0xFFFFFFu) * cmo + k3;
                     e0 = w1 >= thr32 ? e0 : 0.f;
                     e1 = w0 >= thr32 ? e1 : 0.f;
                 }

@@ -102,13 +102,19 @@ def attn_keep(seed, B, H, T, K, p):
     return ops.attn_dropout_keep_mask(seed, B, H, T, K, p)
 
 
+@pytest.mark.parametrize("fwd_gen", [0, 2], ids=["fwd_default", "fwd_16x16"])
 @pytest.mark.parametrize("store_p", [False, True], ids=["recompute", "stored_p"])
 @pytest.mark.parametrize("case", [(64, 0, 2, 2, 64), (40, 24, 2, 2, 32), (130, 0, 1, 1, 64), (200, 70, 3, 2, 64)])
-def test_attention_dropout_fwd_bwd_exact_mask(case, store_p):
+def test_attention_dropout_fwd_bwd_exact_mask(case, store_p, fwd_gen):
+    """Forward and backward regenerate ONE mask (ops.attn_dropout_keep_mask): the default forward of d_head 64 is the
+    transposed 32x32 kernel (relattn3.hip), the backward kernels are the 16x16 family -- different register layouts, the
+    same keep decisions; fwd_16x16 forces the older forward."""
     from commu_amd import ops
     T, M, B, H, DH = case
     if store_p and DH != 64:
         pytest.skip("stored probabilities: d_head 64 kernels only")
+    if fwd_gen == 2 and DH != 64:
+        pytest.skip("one forward kernel for this d_head")
     K, HD, p, seed = T + M, H * DH, 0.2, 424243
     g = torch.Generator().manual_seed(3)
     qkv = bf(torch.randn(K * B, 3 * HD, generator=g) * 0.7)
@@ -127,8 +133,12 @@ def test_attention_dropout_fwd_bwd_exact_mask(case, store_p):
     ref.backward(dout.float())
     gq = qkv.to(DEV)
     q, k, v = gq[M * B:, :HD], gq[:, HD:2 * HD], gq[:, 2 * HD:]
-    out, lse, qs = ops.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M,
-                                   save_q=True, drop_p=p, drop_seed=seed)
+    prev_gen = ops.attn_fwd_generation(fwd_gen)
+    try:
+        out, lse, qs = ops.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M,
+                                       save_q=True, drop_p=p, drop_seed=seed)
+    finally:
+        ops.attn_fwd_generation(prev_gen)
     assert relerr(out, ref) < 1.5e-2
     dqkv = torch.zeros_like(gq)
     drd = torch.zeros(K, HD, device=DEV)
@@ -147,10 +157,12 @@ def test_attention_dropout_fwd_bwd_exact_mask(case, store_p):
     assert relerr(drd, rdl.grad) < tol and relerr(du, ul.grad) < tol and relerr(dvb, vl.grad) < tol
 
 
+@pytest.mark.parametrize("gen", [2, 3])
 @pytest.mark.parametrize("case", [(64, 0, 2, 2), (130, 0, 1, 1), (200, 70, 3, 2), (300, 33, 2, 1)])
-def test_attention_dropout_generation3_forward_exact_mask(case):
-    """relattn3.hip with attention dropout (commu_attn_fwd_generation(3); mask form 2, ops.attn_dropout_keep_mask(version=2))
-    against the oracle with the same mask injected.  Forward only: no backward kernel draws that mask yet."""
+def test_attention_dropout_forward_generations_exact_mask(case, gen):
+    """Both forward kernels of d_head 64 (commu_attn_fwd_generation 2: 16x16 layout, 3: transposed 32x32 layout) with
+    attention dropout against the oracle with the mirror's mask injected; the mask's keep rate and the independence of the
+    four elements of a 2x2 cell (they share the first hash round)."""
     from commu_amd import ops
     T, M, B, H = case
     DH = 64
@@ -159,8 +171,13 @@ def test_attention_dropout_generation3_forward_exact_mask(case):
     qkv = bf(torch.randn(K * B, 3 * HD, generator=g) * 0.7)
     rd = bf(torch.randn(K, HD, generator=g) * 0.7)
     u, vb = torch.randn(HD, generator=g) * 0.3, torch.randn(HD, generator=g) * 0.3
-    keep, pkeep = ops.attn_dropout_keep_mask(seed, B, H, T, K, p, version=2)
+    keep, pkeep = ops.attn_dropout_keep_mask(seed, B, H, T, K, p)
     assert abs(float(keep.float().mean()) - pkeep) < 0.02
+    kf = keep.float()[:, :, :T - T % 2, :K - K % 2]
+    cell = [kf[:, :, a_::2, b_::2] for a_ in range(2) for b_ in range(2)]
+    for x_ in range(4):
+        for y_ in range(x_ + 1, 4):          # P(both kept) = pkeep^2 for any two elements of a cell
+            assert abs(float((cell[x_] * cell[y_]).mean()) - pkeep * pkeep) < 0.03, (x_, y_)
     qf = qkv.float()
     r = rd.float().view(K, H, DH).flip(0)
     S = X.rel_attention_scores(qf[M * B:, :HD].reshape(T, B, H, DH), qf[:, HD:2 * HD].reshape(K, B, H, DH), r,
@@ -169,7 +186,7 @@ def test_attention_dropout_generation3_forward_exact_mask(case):
     A = torch.softmax(S, 3) * keep / pkeep
     ref = torch.einsum("bnij,jbnd->ibnd", A, qf[:, 2 * HD:].reshape(K, B, H, DH)).reshape(T * B, HD)
     gq = qkv.to(DEV)
-    prev = ops.attn_fwd_generation(3)
+    prev = ops.attn_fwd_generation(gen)
     try:
         out, lse, _ = ops.relattn_fwd(gq[M * B:, :HD], gq[:, HD:2 * HD], gq[:, 2 * HD:], rd.to(DEV), u.to(DEV), vb.to(DEV),
                                       None, T, M, B, H, DH, False, M, drop_p=p, drop_seed=seed)
