@@ -293,11 +293,10 @@ typedef struct commu_attn_desc {
  * backward kernels re-use. */
 int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                       hipStream_t stream);
-/* Forward kernel generation for d_head 64 (process-wide; returns the previous value).  0 (default): the 32x32-MFMA /
- * transposed-score kernel (relattn3.hip) without attention dropout, the 16x16-layout kernel with it -- the backward
- * kernels regenerate the dropout mask of the 16x16 family (form 1, pairs of ROWS per hash word).  3: relattn3.hip always;
- * its mask is form 2 (pairs of KEYS per hash word), which no backward kernel draws yet: forward-only use (tests, timing).
- * 2: the 16x16-layout kernel always. */
+/* Forward kernel generation for d_head 64 (process-wide; returns the previous value).  0 (default) and 3: the 32x32-MFMA /
+ * transposed-score kernel (relattn3.hip), with or without attention dropout; 2: the 16x16-layout kernel.  Every attention
+ * kernel -- both forward generations and the backward family -- regenerates the same dropout mask (relattn.hip DropLane: one
+ * mixed word per 2x2 cell of a 32x32 block, one multiply-add per element), so any forward pairs with the backward. */
 int commu_attn_fwd_generation(int gen);
 
 /* Backward of commu_relattn_fwd (autograd of model.py:313-345).  Produces dk, dv, the AC part of dq
