@@ -597,6 +597,26 @@ __global__ void reduce_slabs2d_kernel(float* __restrict__ dst, int ldd, long lon
     const size_t n = (size_t)rows * cols;
     const float* sp = src + (size_t)z * nslabs * stride;
     float* dp = dst + (long long)z * dst_bs;
+    if ((cols & 3) == 0 && (stride & 3) == 0 && (ldd & 3) == 0 && (((size_t)sp | (size_t)dp) & 15) == 0) {
+        // four elements per thread, eight slabs in flight (scalar loads one slab at a time: 94 us for the 64 MB of a layer's
+        // dRd slabs, 0.7 TB/s)
+        for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 8 <= nslabs; k += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(sp + (size_t)(k + u) * stride + i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < nslabs; ++k) s += *(const f32x4*)(sp + (size_t)k * stride + i);
+            const int r = (int)((unsigned)i / (unsigned)cols), c = (int)((unsigned)i - (unsigned)r * (unsigned)cols);
+            f32x4* o = (f32x4*)(dp + (size_t)r * ldd + c);
+            *o = (accumulate ? *o : (f32x4){0.f, 0.f, 0.f, 0.f}) + alpha * s;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nslabs; ++k) s += sp[(size_t)k * stride + i];
@@ -821,7 +841,8 @@ extern "C" int commu_reduce_slabs2d_f32(float* dst, int ldd, long long dst_batch
                                         hipStream_t stream) {
     if (rows <= 0 || cols <= 0 || batch <= 0) return 0;
     if ((size_t)rows * cols >= 0xFFFFFFFFull) return -22;
-    size_t blocks = ((size_t)rows * cols + 255) / 256;
+    size_t blocks = ((size_t)rows * cols / 4 + 255) / 256;          // (four elements per thread on the vector path)
+    if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
     COMMU_LAUNCH(reduce_slabs2d_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, stream, dst, ldd, dst_batch_stride,
                  src, rows, cols, nslabs, stride, accumulate, alpha);
