@@ -80,9 +80,23 @@ def test_g1_forward_backward_vs_reference(golden_dir, tag):
         got = p.grad.detach().float().cpu().flatten()
         worst[name] = relerr(got, ref)
         cosines[name] = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
-    _dump(f"g1_{tag}", {"relerr": worst, "cos": cosines})
+    # Adam's FIRST update of a coordinate is -lr * sign(g) (m / sqrt(v) = g / |g|), so the cosine between the build's and the
+    # reference's first updates of a tensor is the mean SIGN agreement of its gradient -- and a coordinate whose gradient lies
+    # below the bf16 noise of the pass flips its sign half the time however small it is.  sign_cos: that predicted update cosine;
+    # sign_mass: the share of the reference gradient's L1 mass on coordinates whose sign agrees.  (This is what the r_net.weight
+    # window of test_g8 is about: sign_cos is far below 1 there while sign_mass shows that only negligible coordinates flip.)
+    sign_cos, sign_mass = {}, {}
+    for name, p in model.named_parameters():
+        ref = torch.from_numpy(z["g::" + name]).flatten()
+        got = p.grad.detach().float().cpu().flatten()
+        agree = torch.sign(got) == torch.sign(ref)
+        sign_cos[name] = float((torch.sign(got) * torch.sign(ref)).mean())
+        sign_mass[name] = float((ref.abs() * agree).sum() / (ref.abs().sum() + 1e-30))
+    _dump(f"g1_{tag}", {"relerr": worst, "cos": cosines, "sign_cos": sign_cos, "sign_mass": sign_mass})
     # every gradient tensor points the same way as the reference's ...
     assert min(cosines.values()) > 0.995, cosines
+    # ... and whatever coordinates disagree in SIGN carry next to none of the gradient
+    assert min(sign_mass.values()) > 0.995, sign_mass          # (measured >= 0.998; r_net.weight 0.9995-0.9998 at sign_cos 0.70-0.80)
     # ... and matches element-wise to bf16 accuracy (chain through 2 layers).  The first FFN Linear is not held to
     # an element-wise bound HERE: a pre-activation within bf16 rounding of 0 flips its ReLU gate against the fp32
     # reference, which changes one whole term of that unit's weight / bias gradient (36 tokens here) -- a property of
@@ -181,10 +195,15 @@ def test_g8_optimizer_steps_vs_reference(golden_dir):
     _dump("g8", {"cos": cos, "total": total, "norm_ratio": float(allu.norm() / allr.norm())})
     assert total > 0.99, total
     assert abs(float(allu.norm() / allr.norm()) - 1.0) < 0.03
-    # per tensor: >= 0.99 everywhere except r_net.weight (>= 0.8).  Its GRADIENT is as accurate as the others' (1 % of
-    # its range: test_g1_*), but most of its elements lie below the bf16 rounding noise of dS, and Adam turns every
-    # coordinate into a step of size ~lr whatever its magnitude -- measured 0.85 / 0.92; feeding the r_net weight-
-    # gradient GEMM an fp32-accurate (hi + lo bf16) dRd instead of the rounded copy changed neither (0.856 / 0.924).
+    # per tensor: >= 0.99 everywhere except r_net.weight (>= 0.8).  The bound is derived, not tuned: Adam's first update of a
+    # coordinate is -lr * sign(g), so the cosine between two first updates of a tensor IS the mean sign agreement of the two
+    # gradients.  test_g1_forward_backward_vs_reference measures that for every tensor (`sign_cos` in its dump): 0.70-0.80 for
+    # r_net.weight, >= 0.97 elsewhere -- while the coordinates whose sign agrees carry 99.95 % of that gradient's L1 mass
+    # (`sign_mass`, asserted there) and the gradient's own cosine is > 0.995: most of r_net.weight's coordinates (high-frequency
+    # sinusoid inputs, summed over a band whose terms cancel) lie below the bf16 rounding noise of dS, and Adam turns each of
+    # them into a full-size step of random sign.  After 4 steps the second moments damp that a little: measured 0.85 / 0.91.
+    # (Feeding the r_net weight-gradient GEMM an fp32-accurate hi + lo dRd instead of the rounded copy changed neither: the
+    #  noise enters with dS, upstream of that sum.)
     for k, v in cos.items():
         assert v > (0.8 if k.endswith("r_net.weight") else 0.99), (k, v)
 
