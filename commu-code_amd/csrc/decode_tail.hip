@@ -380,10 +380,233 @@ __global__ __launch_bounds__(256) void decode_tail_kernel(TailArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same four phases for WIDE models (d_model 1024, d_inner 2048, 16 heads x 64: BASELINE.json configs[4]).  A workgroup
+// owns 2 .. 6 column tiles per phase and K is 1024 .. 2048, so the weights of a phase no longer fit the register file at
+// once: a phase walks its tiles in BATCHES of two (two waves finish one tile each), the activation fragments stay in
+// registers for the whole phase, LayerNorm parameters are read where they are used.  Hand-offs, counters, packed weight
+// layout and the cache-policy discipline are those of decode_tail_kernel.  (No cross-phase weight prefetch here: the first
+// batch of a phase exposes one L2 round trip.)
+template <int KS>
+__device__ __forceinline__ void layer_norm_wide(bf16x8 (&xf)[KS], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                int d_ln, float eps, float (*st)[16], int w, int r16, int g, int k0) {
+    float mu = 0.f, rs = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float v = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = k0 + 32 * ks + e < d_ln;
+                const float x = in ? bf2f(xf[ks][e]) : 0.f;
+                v += pass == 0 ? x : (in ? (x - mu) * (x - mu) : 0.f);
+            }
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) st[w][r16] = v;
+        __syncthreads();
+        const float t = st[0][r16] + st[1][r16] + st[2][r16] + st[3][r16];
+        if (pass == 0) mu = t / (float)d_ln;
+        else rs = rsqrtf(t / (float)d_ln + eps);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float gm[8], bt[8];
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+            const int kk = min(k0 + 32 * ks + 4 * h4, d_ln - 4);
+            const f32x4 gv = *(const f32x4*)(gamma + kk), bv = *(const f32x4*)(beta + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gm[4 * h4 + e] = gv[e]; bt[4 * h4 + e] = bv[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            xf[ks][e] = f2bf(k0 + 32 * ks + e < d_ln ? (bf2f(xf[ks][e]) - mu) * rs * gm[e] + bt[e] : 0.f);
+    }
+}
+
+// one phase: out tiles ng + 32 t (t < NT) of x . W^T, two tiles per batch; fin(t, v) finishes tile t (called by wave t & 1
+// with the four waves' sum of the lane's 4 outputs: row r16, columns 16 (ng + 32 t) + 4 g .. + 4)
+template <int KS, int NT, class Fin>
+__device__ __forceinline__ void wide_phase(const bf16* __restrict__ Wp, const bf16x8 (&xf)[KS], float (*red)[8][64], int ng, int w,
+                                           int lane, Fin fin) {
+#pragma unroll 1
+    for (int t0 = 0; t0 < NT; t0 += 2) {
+        bf16x8 wf[2][KS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tt = min(t0 + t, NT - 1);
+            const bf16* wp = Wp + ((size_t)(((ng * NT + tt) * 4 + w) * KS) * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[t][ks] = ld_bf16x8(wp + ks * 512);
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = mfma16(wf[t][ks], xf[ks], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[w][4 * t + e][lane] = acc[t][e];
+        __syncthreads();
+        if (w < 2 && t0 + w < NT) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = red[0][4 * w + e][lane] + red[1][4 * w + e][lane] + red[2][4 * w + e][lane] + red[3][4 * w + e][lane];
+            fin(t0 + w, v);
+        }
+        __syncthreads();
+    }
+}
+
+template <int D, int DI, int HD, int MODE>
+__global__ __launch_bounds__(256) void decode_tail_wide_kernel(TailArgs a) {
+    constexpr bool LOGITS = MODE == MODE_LOGITS, HEAD = MODE == MODE_HEAD;
+    constexpr int KS_D = D / 128, KS_DI = DI / 128, KS_HD = HD / 128;
+    constexpr int NT1 = D / 512, NT2 = DI / 512, NT3 = D / 512, NT4 = LOGITS ? 2 : (3 * HD + 511) / 512;
+    static_assert(D % 512 == 0 && DI % 512 == 0 && HD % 128 == 0 && NT3 <= 4, "shape");
+    __shared__ float red[4][8][64];
+    __shared__ float st[4][16];
+    __shared__ __attribute__((aligned(16))) bf16 abuf[NT3][16][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
+    const int ng = blockIdx.x & (NGRP - 1), mg = blockIdx.x >> 5;
+    const int B = a.B, row = 16 * mg + r16;
+    unsigned* cnt = a.sync + mg * CNT_STRIDE;
+    if (HEAD)
+        for (int i = blockIdx.x * 256 + tid; i < a.n_zero; i += gridDim.x * 256) a.zero_words[i] = 0u;
+    const int k0h = w * (32 * KS_HD) + 8 * g, k0d = w * (32 * KS_D) + 8 * g, k0i = w * (32 * KS_DI) + 8 * g;
+    const int rowc = min(row, B - 1);
+    // the lanes that hold columns 16 (ng + 32 t) .. + 16 of a [16 x D] row block whose K range the four waves split
+    auto owns = [&](int t, int& ks_out) {
+        const int c0 = 16 * (ng + NGRP * t);
+        ks_out = (c0 % (32 * KS_D)) / 32;
+        return w == c0 / (32 * KS_D) && (g >> 1) == (c0 % 32) / 16;
+    };
+    // ---------------------------------------------------------------- phase 1: z1 = vec . Wo^T + h
+    if (!HEAD) {
+        bf16x8 xf[KS_HD];
+        load_x<KS_HD>(xf, make_srd(a.vec, ((size_t)(B - 1) * a.ld_vec + HD) * 2), ((unsigned)row * a.ld_vec + k0h) * 2u, false);
+        const srd_t sz1 = make_srd(a.z1, (size_t)B * D * 2);
+        wide_phase<KS_HD, NT1>(a.Wo, xf, red, ng, w, lane, [&](int t, f32x4 v) {
+            const int col = 16 * (ng + NGRP * t) + 4 * g;
+            if (row < B) {
+                const bf16x4 res = *(const bf16x4*)(a.h + (size_t)rowc * a.ld_h + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(res[e]);
+                store4_sc1(sz1, ((unsigned)row * D + col) * 2u, v);
+            }
+        });
+        arrive(cnt, w < 2);
+    }
+    // ---------------------------------------------------------------- phase 2: a = LN1(z1); hid = relu(a . W1^T + b1)
+    if (!HEAD) {
+        bf16x8 xf[KS_D];
+        wait_arrivals(cnt, a.err, 1u);
+        load_x<KS_D>(xf, make_srd(a.z1, (size_t)B * D * 2), ((unsigned)row * D + k0d) * 2u, true);
+        layer_norm_wide<KS_D>(xf, a.g1, a.be1, a.d_ln, a.eps1, st, w, r16, g, k0d);
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) {
+            int oks;
+            if (owns(t, oks)) {
+#pragma unroll
+                for (int ks = 0; ks < KS_D; ++ks)
+                    if (ks == oks) *(bf16x8*)&abuf[t][r16][8 * (g & 1)] = xf[ks];
+            }
+        }
+        const srd_t shid = make_srd(a.hid, (size_t)B * DI * 2);
+        wide_phase<KS_D, NT2>(a.W1, xf, red, ng, w, lane, [&](int t, f32x4 v) {
+            const int col = 16 * (ng + NGRP * t) + 4 * g;
+            if (row < B) {
+                const f32x4 b = *(const f32x4*)(a.b1 + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + b[e], 0.f);
+                store4_sc1(shid, ((unsigned)row * DI + col) * 2u, v);
+            }
+        });
+        arrive(cnt + 4 * CNT_STRIDE, w < 2);
+    }
+    // ---------------------------------------------------------------- phase 3: z2 = hid . W2^T + b2 + a
+    if (!HEAD) {
+        bf16x8 xf[KS_DI];
+        wait_arrivals(cnt + 4 * CNT_STRIDE, a.err, 2u);
+        load_x<KS_DI>(xf, make_srd(a.hid, (size_t)B * DI * 2), ((unsigned)row * DI + k0i) * 2u, true);
+        const srd_t sz2 = make_srd(a.z2, (size_t)B * D * 2);
+        wide_phase<KS_DI, NT3>(a.W2, xf, red, ng, w, lane, [&](int t, f32x4 v) {
+            const int col = 16 * (ng + NGRP * t) + 4 * g;
+            if (row < B) {
+                const f32x4 b = *(const f32x4*)(a.b2 + col);
+                const bf16x4 ra = *(const bf16x4*)&abuf[t][r16][4 * g];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b[e] + bf2f(ra[e]);
+                store4_sc1(sz2, ((unsigned)row * D + col) * 2u, v);
+            }
+        });
+        arrive(cnt + 8 * CNT_STRIDE, w < 2);
+    }
+    // ---------------------------------------------------------------- phase 4: h' = LN2(z2); out = h' . Wn^T (+ bn)
+    {
+        bf16x8 xf[KS_D];
+        if (HEAD) {
+            const long long id = row < B ? a.tok[row] : 0;
+            const bool bad = id < 0 || id >= a.V;
+            const float* src = a.E32 + (size_t)(bad ? 0 : id) * a.d_true;
+#pragma unroll
+            for (int ks = 0; ks < KS_D; ++ks) {
+                const int kk = k0d + 32 * ks;
+                f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (kk < a.d_true) v0 = *(const f32x4*)(src + kk);
+                if (kk + 4 < a.d_true) v1 = *(const f32x4*)(src + kk + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = bad ? __builtin_nanf("") : (e < 4 ? v0[e & 3] : v1[e & 3]) * a.emb_scale;
+                    xf[ks][e] = f2bf(kk + e < a.d_true ? x : 0.f);
+                }
+            }
+        } else {
+            wait_arrivals(cnt + 8 * CNT_STRIDE, a.err, 3u);
+            load_x<KS_D>(xf, make_srd(a.z2, (size_t)B * D * 2), ((unsigned)row * D + k0d) * 2u, true);
+            layer_norm_wide<KS_D>(xf, a.g2, a.be2, a.d_ln, a.eps2, st, w, r16, g, k0d);
+        }
+        if (row < B && a.h_out != nullptr) {
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) {
+                int oks;
+                if (owns(t, oks)) {
+#pragma unroll
+                    for (int ks = 0; ks < KS_D; ++ks)
+                        if (ks == oks) st_bf16x8(a.h_out + (size_t)row * a.ld_ho + 16 * (ng + NGRP * t) + 8 * (g & 1), xf[ks]);
+                }
+            }
+        }
+        wide_phase<KS_D, NT4>(a.Wn, xf, red, ng, w, lane, [&](int t, f32x4 v) {
+            const int col = 16 * (ng + NGRP * t) + 4 * g;
+            if (row < B && col < a.Nn && !(LOGITS && a.active != nullptr && !a.active[row])) {
+                if (LOGITS) {
+                    float* o = (float*)a.out_n + (size_t)row * a.ld_on + col;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < a.Nn) o[e] = v[e] + a.bn[min(col + e, a.Nn - 1)];
+                } else {
+                    bf16* o = (bf16*)a.out_n + (size_t)row * a.ld_on + col;
+                    *(bf16x4*)o = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                }
+            }
+        });
+    }
+}
+
 }  // namespace
 
 extern "C" int commu_decode_tail_supported(int B, int D, int DI, int HD) {
-    return (B >= 1 && B <= 64 && D == 512 && DI == 1024 && (HD == 512 || HD == 640)) ? 1 : 0;
+    if (B < 1 || B > 64) return 0;
+    if (D == 512 && DI == 1024 && (HD == 512 || HD == 640)) return 1;
+    if (D == 1024 && DI == 2048 && HD == 1024) return 1;          // decode_tail_wide_kernel
+    return 0;
 }
 
 extern "C" int commu_decode_tail_sync_words(void) { return 12 * CNT_STRIDE; }
@@ -445,7 +668,10 @@ extern "C" int commu_decode_layer_tail(const void* vec, int ld_vec, const void* 
     a.out_n = out_n; a.ld_on = ld_on;
     a.B = B; a.sync = sync; a.err = err; a.active = active;
     const dim3 grid(NGRP * ((B + 15) / 16));
-    if (HD == 512) {
+    if (D == 1024) {
+        if (logits) COMMU_LAUNCH((decode_tail_wide_kernel<1024, 2048, 1024, MODE_LOGITS>), grid, dim3(256), 0, stream, a);
+        else COMMU_LAUNCH((decode_tail_wide_kernel<1024, 2048, 1024, MODE_QKV>), grid, dim3(256), 0, stream, a);
+    } else if (HD == 512) {
         if (logits) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_LOGITS>), grid, dim3(256), 0, stream, a);
         else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_QKV>), grid, dim3(256), 0, stream, a);
     } else {          // 10 heads x 64: the released default config (d_model 500, 10 x 50) after zero padding
@@ -468,7 +694,8 @@ extern "C" int commu_decode_head(const int64_t* tok, const float* E, int d_true,
     a.out_n = qkv; a.ld_on = ld_qkv;
     a.B = B; a.zero_words = zero_words; a.n_zero = zero_words != nullptr ? n_zero : 0;
     const dim3 grid(NGRP * ((B + 15) / 16));
-    if (HD == 512) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_HEAD>), grid, dim3(256), 0, stream, a);
+    if (D == 1024) COMMU_LAUNCH((decode_tail_wide_kernel<1024, 2048, 1024, MODE_HEAD>), grid, dim3(256), 0, stream, a);
+    else if (HD == 512) COMMU_LAUNCH((decode_tail_kernel<512, 1024, 512, MODE_HEAD>), grid, dim3(256), 0, stream, a);
     else COMMU_LAUNCH((decode_tail_kernel<512, 1024, 640, MODE_HEAD>), grid, dim3(256), 0, stream, a);
     COMMU_LAUNCH_CHECK();
     return 0;

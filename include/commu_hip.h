@@ -405,8 +405,8 @@ int commu_decode_advance(int* klen, const unsigned char* advance, int B, int Lma
  * z1 / z2 [B][D] and hid [B][DI] are dense bf16 hand-off buffers that belong to THIS layer; sync:
  * commu_decode_tail_sync_words() arrival counters that must be ZERO on entry (one set per launch of a step); *err
  * becomes non-zero when a workgroup gave up waiting (the results of that launch are then invalid).
- * commu_decode_tail_supported(B, D, DI, HD) names the shapes this build takes (others: -22; callers use the
- * per-Linear launches).  d_ln: LayerNorm width (<= D; zero-padded models). */
+ * commu_decode_tail_supported(B, D, DI, HD) names the shapes this build takes -- (512, 1024, 8 or 10 heads x 64) and the
+ * wide (1024, 2048, 16 x 64), up to 64 sequences -- (others: -22; callers use the per-Linear launches).  d_ln: LayerNorm width (<= D; zero-padded models). */
 int commu_decode_tail_supported(int B, int D, int DI, int HD);
 /* diagnostics: following layer-tail / head launches write 100 MHz timestamps of their phase boundaries to
  * buf[workgroup][16] (device memory, 128 x 16 words; null: off) */

@@ -476,11 +476,13 @@ def test_split_key_decode_attention_matches_the_unsplit_kernel(loaded):
 
 @pytest.mark.parametrize("B,loaded,shape", [(64, False, (6, 8, 512, 1024)), (64, True, (6, 8, 512, 1024)),
                                             (37, False, (6, 8, 512, 1024)), (3, True, (6, 8, 512, 1024)),
-                                            (64, True, (6, 10, 500, 1000)), (5, False, (6, 10, 500, 1000))])
+                                            (64, True, (6, 10, 500, 1000)), (5, False, (6, 10, 500, 1000)),
+                                            (64, True, (3, 16, 1024, 2048)), (21, False, (3, 16, 1024, 2048))])
 def test_layer_tail_launch_matches_the_per_linear_chain(B, loaded, shape):
     """commu_decode_layer_tail (four Linears + two LayerNorms of a layer as phases of one launch, hand-offs between
     workgroups inside the launch) against the chain of per-Linear launches it replaces, on the same model, caches and
-    tokens, for 160 consecutive steps: every step's logits within bf16 rounding of each other (a stale or torn hand-off
+    tokens (the last two shapes: d_model 1024 / d_inner 2048 / 16 heads, decode_tail_wide_kernel), for 160 consecutive steps:
+    every step's logits within bf16 rounding of each other (a stale or torn hand-off
     would be an O(1) error in some row), the caches equal at the end, no workgroup gave up.  `loaded`: a second stream
     keeps the GPU busy with large GEMMs meanwhile, so the workgroups of a launch start and run unevenly."""
     import commu_amd.generate as G
