@@ -326,7 +326,10 @@ typedef struct commu_attn_bwd_desc {
     void* p_scratch;      /* NULL, or (d_head 64 only) commu_attn_p_scratch_elems(T, M, B, H) bf16 elements, uninitialised:
                              the query-stationary kernel stores the probabilities it recomputes there and the
                              key-stationary kernel, which must then run AFTER it on the same stream, reads them
-                             back instead of recomputing (q+u).k, the band product / rel-shift, masks and exp */
+                             back instead of recomputing (q+u).k, the band product / rel-shift, masks and exp.  The
+                             buffer is private to that pair of launches: its block order is the key-stationary kernel's
+                             read order, and with attention dropout a stored value is NEGATIVE where the mask drops the
+                             element (the keep decision travels in the sign; that kernel does not hash) */
     const void* o;        /* NULL, or the forward output (bf16 [T*B][ld_o]): the query-stationary kernel then computes
                              delta[b,h,i] = sum_d o . dout itself (commu_attn_delta is not needed) and WRITES it to
                              `delta` for the key-stationary kernel, which must run after it on the same stream */
