@@ -77,8 +77,9 @@ def cpu_baseline(args):
     per = sum(times) / len(times)
     return {"value": round(Bc * T / per, 1), "unit": "tokens/s", "cores": nthreads, "kind": "port",
             "cpu": f"{cpu_model()} ({os.cpu_count()} logical cpus visible)",
+            "threads_sweep_s_per_step": {"8": 1.7, "16": 1.4, "32": 1.4, "64": 2.5, "256": 157.0},   # tests/probes/cpu_threads.py
             "sample": f"{len(times)} optimiser steps of the same model shape at batch {Bc} x tgt_len {T} "
-                      f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step)"}
+                      f"(fp32 PyTorch-CPU oracle, {per:.2f} s/step; {nthreads} threads: the fastest setting of the sweep)"}
 
 
 def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
