@@ -570,6 +570,49 @@ def test_decoder_reused_after_a_weight_update():
     assert after != before
 
 
+def test_wide_model_decoder_graph_and_layer_tail():
+    """The decode loop of a wide model (d_model 1024, d_inner 2048, 16 heads: the width of BASELINE.json configs[4]) through
+    decode_tail_wide_kernel: the captured iteration graph replays the eager launches token for token, and the sampled
+    sequences (same variates) equal those of the per-Linear chain."""
+    import commu_amd.generate as G
+    from commu_amd.generate import ForcedDecoder
+    from test_configs_gpu import build
+    model, cfg, s, params = build(3, 16, 1024, 2048, 1, 4146, seed=41)
+    model.eval()
+    model.same_length = True
+    model.reset_length(1, 4146)
+    with torch.no_grad():
+        bias = model.crit.out_layers[0].bias
+        bias.zero_()
+        bias[1:3] = -1e9
+        bias[195:304] = -1e9
+    meta = [574, 623, 627, 635, 639, 642, 651, 684, 694, 720, 727]
+    data = types.SimpleNamespace(num_measures=4.0, chord_token_components={"chord_token": [], "chord_position": []})
+    uni = np.random.RandomState(9).random_sample((6, 64)).astype(np.float32)
+
+    def run(graph):
+        dec = ForcedDecoder(model, 6, generation_length=48, memory_length=4146, temperature=0.95, top_k=32)
+        dec.load([meta] * 6, [data] * 6, uni)
+        with torch.no_grad():
+            dec.run(use_graph=graph)
+        dec.state.check()
+        return dec, dec.sequences()[0]
+    dec_g, seq_g = run(True)
+    assert dec_g.state.tail_ok
+    _, seq_e = run(False)
+    assert seq_g == seq_e
+    G.USE_LAYER_TAIL = False
+    try:
+        _, seq_chain = run(False)
+    finally:
+        G.USE_LAYER_TAIL = True
+    # (bf16 rounding differs between the two step implementations: a draw that sits on a probability boundary may differ;
+    #  the sequences must agree on almost every token and exactly up to the first such draw)
+    same = sum(int(a == b) for sa, sb in zip(seq_g, seq_chain) for a, b in zip(sa, sb))
+    total = sum(min(len(sa), len(sb)) for sa, sb in zip(seq_g, seq_chain))
+    assert total > 0 and same >= 0.9 * total, (same, total)
+
+
 def test_generate_stream_rearms_finished_slots():
     """BatchedGenerator.generate_stream: 150 attempts of one request through 64 slots, a finished slot re-armed with the
     next attempt while the others keep decoding.  Every attempt draws from its own variate stream, so its sequence must
