@@ -132,6 +132,12 @@ def attn_fwd_generation(gen: int) -> int:
     return call("commu_attn_fwd_generation", int(gen))
 
 
+def attn_bwd_kv_generation(gen: int) -> int:
+    """commu_attn_bwd_kv_generation: 0 automatic, 2 / 3 force a key-stationary backward kernel for d_head 64 with stored
+    probabilities; returns the previous value."""
+    return call("commu_attn_bwd_kv_generation", int(gen))
+
+
 def _rowmajor2d(t: torch.Tensor, name: str):
     if t.dim() != 2 or t.stride(1) != 1:
         raise ValueError(f"{name}: need a 2-D tensor with unit column stride, got {tuple(t.shape)} / {t.stride()}")

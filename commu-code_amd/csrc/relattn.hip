@@ -864,9 +864,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // bookkeeping as certainly younger than the staging loads, so its counted waits for those loads (bottom of the tile)
     // also waited for this tile's four P stores to be ACKNOWLEDGED -- a round trip to memory per tile.
     const bool pstore = a.pbuf != nullptr && i0 + 16 * w < T;
-    const srd_t srdP = make_srd(a.pbuf + ((size_t)b * a.H + h) * ((T + 15) >> 4) * JT * 1024,
-                                pstore ? (size_t)((T + 15) >> 4) * JT * 2048 : 0);
-    const int pvoff = pt_off(r16, g) * 2;          // bytes; pt_off(16c + r16, g) = 256 c + pt_off(r16, g)
+    // (p_layout 1, relattn_bwd_kv3_kernel: 2-KB blocks of 32 queries x 32 keys; this wave's rows are half (w & 1) of block row
+    //  iw_lo >> 5, key block c of the tile is half (c & 1) of block column 2 jt + (c >> 1); a lane's 8 bytes -- four queries of
+    //  one key -- sit at key * 64 + (g & 1) * 32 + (2 (w & 1) + (g >> 1)) * 8 of the block)
+    const size_t pblocks = a.p_layout ? (size_t)(2 * ((T + 31) >> 5)) * JT : (size_t)((T + 15) >> 4) * JT;
+    const srd_t srdP = make_srd(a.pbuf + ((size_t)b * a.H + h) * pblocks * 1024, pstore ? pblocks * 2048 : 0);
+    const int pvoff = a.p_layout ? r16 * 64 + (g & 1) * 32 + (2 * (w & 1) + (g >> 1)) * 8
+                                 : pt_off(r16, g) * 2;          // bytes; pt_off(16c + r16, g) = 256 c + pt_off(r16, g)
     int foff[KS];          // fragment addressing: lane part r16 * DH + swizzled chunk (block rows are multiples of 16)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) foff[ks] = r16 * DH + (((4 * ks + g) ^ (swz<DH>(r16) & (DH / 8 - 1))) << 3);
@@ -976,8 +980,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             // the key-stationary kernel re-reads P instead of recomputing it (block of 16 rows x 64 keys, P^T image order)
             if (DH == 64)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), srdP, pvoff + 512 * c,
-                                                      (((iw_lo >> 4) * JT + jt) << 11), 2 /* nt: read once, by a later kernel */);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pq), srdP,
+                                                      pvoff + (a.p_layout ? 1024 * (c & 1) + 2048 * (c >> 1) : 512 * c),
+                                                      a.p_layout ? (((iw_lo >> 5) * 2 * JT + 2 * jt) << 11) : (((iw_lo >> 4) * JT + jt) << 11),
+                                                      2 /* nt: read once, by a later kernel */);
             *(bf16x4*)(myD + pt_off(16 * c + r16, g)) = db;       // dS^T[kv][row]
             // by distance: (row 4g+reg, jj = 16c + r16) -> ring column (i + M - j0 - jj) & 127
 #pragma unroll
@@ -1504,7 +1510,15 @@ static bool fits_srd(const commu_attn_desc* d) {
 
 /* elements of the P scratch the backward pass may be given (commu_attn_bwd_desc.p_scratch) */
 extern "C" long long commu_attn_p_scratch_elems(int T, int M, int B, int H) {
-    return (long long)B * H * ((T + 15) / 16) * ((T + M + 63) / 64) * 1024;
+    return (long long)B * H * (2 * ((T + 31) / 32)) * ((T + M + 63) / 64) * 1024;          // (covers both block orders)
+}
+
+constexpr bool KV3_DEFAULT = false;          // the automatic choice (generation 0)
+static int g_kv_gen = 0;
+extern "C" int commu_attn_bwd_kv_generation(int gen) {
+    const int prev = g_kv_gen;
+    if (gen == 0 || gen == 2 || gen == 3) g_kv_gen = gen;
+    return prev;
 }
 
 static int g_fwd_gen = 0;
@@ -1582,13 +1596,18 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     dim3 gq((((d->T + 63) / 64 + 1) / 2) * d->H * d->B), gk((((K + 63) / 64 + 1) / 2) * d->H * d->B);
     const bool drop = a.drop_thr != 0u;
     if (a.pbuf != nullptr) {          // the query-stationary kernel stores P, the key-stationary one reads it back
+        // (commu_attn_bwd_kv_generation: 3 = relattn_kv3.hip, 32 keys per wave on the 32x32 MFMA; the two launches of a
+        //  backward pass must see the same setting -- it fixes the block order of the P scratch)
+        const bool kv3 = KV3_DEFAULT ? g_kv_gen != 2 : g_kv_gen == 3;
+        a.p_layout = kv3 ? 1 : 0;
         if (drop) {
             if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, true>), gq, dim3(256), 0, stream, a);
-            if (which & 2) COMMU_LAUNCH((relattn_bwd_kv2_kernel<true>), gk, dim3(256), 0, stream, a);
+            if ((which & 2) && !kv3) COMMU_LAUNCH((relattn_bwd_kv2_kernel<true>), gk, dim3(256), 0, stream, a);
         } else {
             if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, false>), gq, dim3(256), 0, stream, a);
-            if (which & 2) COMMU_LAUNCH((relattn_bwd_kv2_kernel<false>), gk, dim3(256), 0, stream, a);
+            if ((which & 2) && !kv3) COMMU_LAUNCH((relattn_bwd_kv2_kernel<false>), gk, dim3(256), 0, stream, a);
         }
+        if ((which & 2) && kv3) launch_relattn_bwd_kv3(a, stream);
         COMMU_LAUNCH_CHECK();
         return 0;
     }

@@ -27,6 +27,8 @@ struct AttnArgs {
     bf16* dsk;          // [H][T*B][ld_dsk]  dS indexed by distance d (zero-initialised by the caller)
     float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
     bf16* pbuf;         // P scratch [B*H][ceil(T/16)][ceil(K/64)][64 keys][16 rows]: written by bwd_q, read by bwd_kv2 (or null)
+    int p_layout;       // 0: the block order above; 1: [B*H][ceil(T/32)][2 ceil(K/64)] blocks of [32 keys][2 halves][4][4 queries],
+                        //    the accumulator order of relattn_bwd_kv3_kernel
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
     int dsk_wedge;      // > 0: dsk is uninitialised; zero columns i+M+1 .. i+M+dsk_wedge of every row (band GEMM contract)
     int dsk_tiled;      // != 0: dsk is stored as [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (band.hip)
@@ -39,6 +41,8 @@ struct AttnArgs {
 
 // relattn3.hip (d_head 64): forward on the 32x32 MFMA / transposed-score layout
 int launch_relattn_fwd3(const AttnArgs& a, hipStream_t stream);
+// relattn_kv3.hip (d_head 64): key-stationary backward from stored probabilities (p_layout 1) on the same MFMA
+int launch_relattn_bwd_kv3(const AttnArgs& a, hipStream_t stream);
 
 namespace {
 

@@ -298,6 +298,10 @@ int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2
  * kernel -- both forward generations and the backward family -- regenerates the same dropout mask (relattn.hip DropLane: one
  * mixed word per 2x2 cell of a 32x32 block, one multiply-add per element), so any forward pairs with the backward. */
 int commu_attn_fwd_generation(int gen);
+/* Key-stationary backward kernel for d_head 64 with a P scratch (process-wide; returns the previous value).  3: relattn_kv3.hip
+ * (32 keys per wave on the 32x32 MFMA); 2: the 16x16-layout kernel; 0: the build's default.  The setting fixes the block order in
+ * which commu_relattn_bwd_q writes the scratch: both launches of a backward pass must see the same value. */
+int commu_attn_bwd_kv_generation(int gen);
 
 /* Backward of commu_relattn_fwd (autograd of model.py:313-345).  Produces dk, dv, the AC part of dq
  * and dS indexed by distance; the caller finishes with two GEMMs per head:

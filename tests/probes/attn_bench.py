@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "commu-code_amd"))
 import torch  # noqa: E402
 from commu_amd import ops  # noqa: E402
-ops.attn_fwd_generation(int(os.environ.get("COMMU_ATTN_FWD_GEN", "0")))      # 3: relattn3.hip also with dropout
+ops.attn_fwd_generation(int(os.environ.get("COMMU_ATTN_FWD_GEN", "0")))      # 2: the 16x16-layout forward
+ops.attn_bwd_kv_generation(int(os.environ.get("COMMU_ATTN_KV_GEN", "0")))     # 2 / 3: key-stationary backward kernel
 
 B = int(os.environ.get("AB_B", 16))
 T = int(os.environ.get("AB_T", 1024))

@@ -103,7 +103,7 @@ def attn_keep(seed, B, H, T, K, p):
 
 
 @pytest.mark.parametrize("fwd_gen", [0, 2], ids=["fwd_default", "fwd_16x16"])
-@pytest.mark.parametrize("store_p", [False, True], ids=["recompute", "stored_p"])
+@pytest.mark.parametrize("store_p", [False, True, 3], ids=["recompute", "stored_p", "stored_p_kv3"])
 @pytest.mark.parametrize("case", [(64, 0, 2, 2, 64), (40, 24, 2, 2, 32), (130, 0, 1, 1, 64), (200, 70, 3, 2, 64)])
 def test_attention_dropout_fwd_bwd_exact_mask(case, store_p, fwd_gen):
     """Forward and backward regenerate ONE mask (ops.attn_dropout_keep_mask): the default forward of d_head 64 is the
@@ -143,12 +143,14 @@ def test_attention_dropout_fwd_bwd_exact_mask(case, store_p, fwd_gen):
     dqkv = torch.zeros_like(gq)
     drd = torch.zeros(K, HD, device=DEV)
     du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
-    keep_flag, ops.STORE_ATTN_P = ops.STORE_ATTN_P, store_p
+    keep_flag, ops.STORE_ATTN_P = ops.STORE_ATTN_P, bool(store_p)
+    prev_kv = ops.attn_bwd_kv_generation(3 if store_p == 3 else 2)
     try:
         ops.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M, out, dout.to(DEV), lse,
                         qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=p, drop_seed=seed)
     finally:
         ops.STORE_ATTN_P = keep_flag
+        ops.attn_bwd_kv_generation(prev_kv)
     gref = leaf.grad
     tol = 3e-2
     assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol

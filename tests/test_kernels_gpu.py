@@ -686,7 +686,7 @@ def test_relattn_bwd_delta_inside_the_query_kernel():
         assert relerr(b_, a_) < 2e-3
 
 
-@pytest.mark.parametrize("store_p", [False, True], ids=["recompute", "stored_p"])
+@pytest.mark.parametrize("store_p", [False, True, 3], ids=["recompute", "stored_p", "stored_p_kv3"])
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_relattn_bwd(case, store_p):
     """store_p: the query-stationary kernel writes the probabilities it recomputes into a scratch buffer (poisoned with
@@ -719,13 +719,17 @@ def test_relattn_bwd(case, store_p):
     out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len,
                                  save_q=True)
     o.POISON_SCRATCH = True           # NaN in every scratch element the kernels are not supposed to read
-    keep_flag, o.STORE_ATTN_P = o.STORE_ATTN_P, store_p
+    keep_flag, o.STORE_ATTN_P = o.STORE_ATTN_P, bool(store_p)
+    # (stored_p_kv3: the key-stationary kernel of relattn_kv3.hip -- 32 keys per wave on the 32x32 MFMA -- and the block order
+    #  of the scratch that goes with it; stored_p: the 16x16-layout kernel)
+    prev_kv = o.attn_bwd_kv_generation(3 if store_p == 3 else 2)
     try:
         o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
                       dout.to(DEV), lse, qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
     finally:
         o.POISON_SCRATCH = False
         o.STORE_ATTN_P = keep_flag
+        o.attn_bwd_kv_generation(prev_kv)
     gref = leaf.grad
     tol = 2.5e-2          # bf16 P/dS operands + bf16 outputs
     assert relerr(dqkv[M * B:, :HD], gref[M * B:, :HD]) < tol, "dq"
