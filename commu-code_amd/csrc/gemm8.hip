@@ -306,18 +306,20 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
         voffW[j] = (unsigned)(wcol * a.ldb + c * 8) * 2u;
     }
     const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
+    const srd_t srdA = mk_srd(a.A, 0, a.M, a.lda, a.K), srdB = mk_srd(a.B, 0, a.N, a.ldb, a.K);
     auto stage = [&](int q, const Cur& c, int pb) {
         if (ABL == 2 && c.i + c.kt > 1) return;
         const unsigned dst = lds0 + pb * BUF_BYTES + q * HT_BYTES + w * 2048;
-        const unsigned soff = (unsigned)c.kt * 128u;
+        // (ONE descriptor per operand for the whole kernel; the tile's first row travels in the scalar offset with the K offset:
+        //  a descriptor per call cost ~20 scalar instructions and two branches, four times per K-tile)
         if (q == Q_XLO || q == Q_XHI) {
-            const srd_t s = mk_srd(a.A, c.m0 + (q == Q_XHI ? 64 : 0), a.M, a.lda, a.K);
-            dma16(s, voffX[0], soff, dst);
-            dma16(s, voffX[1], soff, dst + 1024);
+            const unsigned soff = (unsigned)(c.m0 + (q == Q_XHI ? 64 : 0)) * (unsigned)a.lda * 2u + (unsigned)c.kt * 128u;
+            dma16(srdA, voffX[0], soff, dst);
+            dma16(srdA, voffX[1], soff, dst + 1024);
         } else {
-            const srd_t s = mk_srd(a.B, c.n0 + (q == Q_WHI ? 32 : 0), a.N, a.ldb, a.K);
-            dma16(s, voffW[0], soff, dst);
-            dma16(s, voffW[1], soff, dst + 1024);
+            const unsigned soff = (unsigned)(c.n0 + (q == Q_WHI ? 32 : 0)) * (unsigned)a.ldb * 2u + (unsigned)c.kt * 128u;
+            dma16(srdB, voffW[0], soff, dst);
+            dma16(srdB, voffW[1], soff, dst + 1024);
         }
     };
 
