@@ -11,7 +11,7 @@ out=$PWD/gpurun_out/r04_attention_pmc.txt
   echo "# values summed over the device per dispatch; SQ_*CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles)"
   echo "## relattn_fwd3 (generation 3), no dropout"
   bash tests/probes/pmc_fwd3.sh relattn_fwd3 3 0.0 2>&1 | grep -v "^$"
-  echo "## relattn_fwd3 (generation 3), dropout 0.1 (mask form 2)"
+  echo "## relattn_fwd3 (generation 3), dropout 0.1"
   bash tests/probes/pmc_fwd3.sh relattn_fwd3 3 0.1 2>&1 | grep -v "^$"
   export AB_DROP=0.1 AB_B=64
   for k in relattn_fwd2 relattn_bwd_q relattn_bwd_kv2 band_bwd; do
