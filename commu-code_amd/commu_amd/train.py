@@ -78,6 +78,7 @@ class Trainer:
         once and moved to the collector's permanent generation (gc.freeze): a full collection of a process with torch
         loaded walks ~1e6 objects, 70-80 ms on the MI355X host -- fourteen steps' worth at 8 sequences per GPU -- and the
         step's own short-lived containers trigger one every few dozen steps otherwise (profiles/r04_b8_gc.txt)."""
+        self._one = None
         self.settle_heap = bool(settle_heap)
         self._heap_settled = False
         self.model, self.cfg, self.num_gpus, self.reducer, self.pad_id = model, cfg, num_gpus, reducer, pad_id
@@ -135,7 +136,10 @@ class Trainer:
                 self.reducer.begin()
                 model.grad_ready_hook = self.reducer.range_ready
             try:
-                loss.backward()
+                # (a cached scalar 1 as the seed gradient: the engine's own ones_like is a fill launch per micro-batch)
+                if self._one is None or self._one.device != loss.device:
+                    self._one = torch.ones((), device=loss.device, dtype=loss.dtype)
+                loss.backward(self._one)
             finally:
                 model.grad_ready_hook = None
             total = loss.detach() if total is None else total + loss.detach()
