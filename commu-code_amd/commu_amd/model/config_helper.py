@@ -34,6 +34,14 @@ class CfgNode(dict):
     def defrost(self):
         self._set_frozen(False)
 
+    def clone(self):
+        """Deep copy (yacs CfgNode.clone), defrosted state preserved per node."""
+        out = CfgNode()
+        for k, v in self.items():
+            out[k] = v.clone() if isinstance(v, CfgNode) else v
+        object.__setattr__(out, "_frozen", object.__getattribute__(self, "_frozen"))
+        return out
+
     def __str__(self):
         def fmt(node, ind):
             out = []

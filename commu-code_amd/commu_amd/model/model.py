@@ -809,6 +809,11 @@ class MemTransformerLM(nn.Module):
                 part, gv(pre + "dec_attn.layer_norm.weight", (Dt,)), gv(pre + "dec_attn.layer_norm.bias", (Dt,)), group=cgrp))
             wgrad(dz1m, sv.vec[i], gv(pre + "dec_attn.o_net.weight", (Dt, HDt)), crop=spec("o"))
             last = i == 0
+            # Under an overlapped gradient exchange (no column-sum group) the LAST layer's bias chain runs on the second
+            # side stream while its qkv weight gradient -- whose slabs would carry the colsum(dq) term of d r_r_bias --
+            # is reduced on the first one: two unordered read-modify-writes of one vector.  There the term stays in the
+            # bias chain (one stream, stream order), as for every layer before the weight-gradient launch carried it.
+            hook_last = last and cgrp is None and side is not None
             if last:
                 # the last layer of the pass: nothing follows its weight gradients on the main stream but one GEMM and the
                 # embedding scatter, so w2 | w1 | o leave now (beside this layer's attention backward) and only qkv remains
@@ -827,7 +832,7 @@ class MemTransformerLM(nn.Module):
                             sv.lse[i], sv.qs[i], dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, gu, gvb,
                             drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale,
                             scratch=scr[i & 1], defer=(defer_last if last else defer) if side is not None else None,
-                            colsum_group=cgrp, dq_colsum=False)
+                            colsum_group=cgrp, dq_colsum=hook_last)
             gWr = gv(pre + "dec_attn.r_net.weight", (HDt, Dt))
             if side is None:
                 self._tn_acc(ops.cast_bf16(drd), sv.pd, gWr, crop=spec("r"))
@@ -844,7 +849,7 @@ class MemTransformerLM(nn.Module):
                     defer(mark_free)
             gW = gv(pre + "dec_attn.qkv_net.weight", (3 * HDt, Dt))
             # (d r_r_bias's colsum(dq) term = the first H*DH column sums of dqkv: from the weight-gradient launch)
-            wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"), colsum=(gvb, HD))
+            wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"), colsum=None if hook_last else (gvb, HD))
             if M > 0:
                 wgrad(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
             flush_wgrads()
@@ -897,9 +902,8 @@ class MemTransformerLM(nn.Module):
         """items = [(dY, X, gW, rows, crop), ...] with a common token count: gW (+)= dY^T X for each, one grouped
         launch + one reduce per problem; falls back to _tn_acc when the grouped kernel does not take the shapes."""
         fl = self._flat
-        ncs = sum(1 for it in items if it[5] is not None)
         arr, Mtok, offs, total, cs_offs = ops.tn_group([(it[0], it[1]) for it in items], colsum=[it[5] is not None for it in items])
-        ns = ops.tn_group_slices(arr, Mtok) if len(items) + ncs <= 8 else 0          # (one reduce launch: <= 8 destinations)
+        ns = ops.tn_group_slices(arr, Mtok)          # (<= 8 problems; the reductions below go in launches of <= 8 destinations)
         if ns <= 0:
             for dY, Xa, gW, rows, crop, cs in items:
                 self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)
@@ -931,7 +935,7 @@ class MemTransformerLM(nn.Module):
             lo = item[0].data_ptr()
             hi = lo + item[0].numel() * item[0].element_size()
             for bt in batches:
-                if all(hi <= l2 or h2 <= lo for l2, h2, _ in bt):
+                if len(bt) < 8 and all(hi <= l2 or h2 <= lo for l2, h2, _ in bt):
                     bt.append((lo, hi, item))
                     break
             else:

@@ -64,7 +64,7 @@ class Trainer:
 
     MERGE_MAX_ROWS = 65536          # tokens (T x B) up to which the micro-batches of a step are run as ONE pass
 
-    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0, graph=False, merge_chunks=None, settle_heap=True):
+    def __init__(self, model, cfg, num_gpus=1, reducer=None, pad_id=0, graph=False, merge_chunks=None, settle_heap=False):
         """merge_chunks: the reference splits a batch into `batch_chunk` micro-batches to fit its GPU's memory
         (train.py:113-155); each contributes mean(loss over ITS non-pad targets) / batch_chunk.  With 288 GB of HBM the
         columns of all micro-batches go through ONE forward / backward whose loss weights every token by
@@ -74,8 +74,10 @@ class Trainer:
         graph=True: once the step's shapes are steady (XL memory at its full length) the device work of a step is
         captured in two hipGraphs -- [all micro-batches forward + backward] and [clip + Adam + weight shadows] -- and
         replayed; the gradient exchange of a multi-GPU job runs between the two replays.  See _graph_step.
-        settle_heap: after the first step (model, optimiser state, module tables all exist) the Python heap is collected
-        once and moved to the collector's permanent generation (gc.freeze): a full collection of a process with torch
+        settle_heap (OPT-IN: a process-wide side effect -- the application's own objects alive at that moment are frozen
+        too and cyclic garbage among them is never reclaimed; train.py and bench.py of this package switch it on): after
+        the first step (model, optimiser state, module tables all exist) the Python heap is collected
+        ONCE and moved to the collector's permanent generation (gc.freeze): a full collection of a process with torch
         loaded walks ~1e6 objects, 70-80 ms on the MI355X host -- fourteen steps' worth at 8 sequences per GPU -- and the
         step's own short-lived containers trigger one every few dozen steps otherwise (profiles/r04_b8_gc.txt)."""
         self._one = None
@@ -308,8 +310,7 @@ class Trainer:
             # hand the live memories to the graph: from now on they live in its static buffers (the list is the
             # trainer's own: an eager step may rebind its entries without touching the graph's)
             self.mems = list(self._graph_state["mems"])
-            if self.settle_heap:
-                self._settle_heap()                           # the captured graphs' host objects are long-lived too
+            # (no second gc.freeze after a capture: settling is done once per trainer, after its first step)
         st = self._graph_state
         fl = model._flat
         if fl.get("shadow_ready") is not None:                # an EAGER step ran since the last replay: its transposed
@@ -359,25 +360,49 @@ class Trainer:
         tok_all, nll_all = self._sum_over_ranks([tok, nll / 10000.0])
         return int(tok_all), nll_all / (max(tok_all, 1.0) / 10000.0)
 
-    @torch.no_grad()
     def evaluate(self, eval_iter):
         """train.py:74-110: same_length evaluation with the longer EVALUATE memory."""
-        cfg, model = self.cfg, self.model
-        model.eval()
-        model.reset_length(tgt_len=cfg.EVALUATE.tgt_length, mem_len=cfg.EVALUATE.mem_length)
-        model.same_length = True
-        total_tok, total_nll = 0, 0.0
-        mems = None
-        for data, target, all_reset, ntok in eval_iter():
-            if all_reset:
-                mems = None
-            loss, mems = model(data, target, None, mems)
-            total_nll += ntok * float(masked_mean(loss, target, self.pad_id, 1.0))
-            total_tok += ntok
-        model.reset_length(cfg.TRAIN.tgt_length, cfg.TRAIN.mem_length)
-        model.same_length = cfg.MODEL.same_length
-        model.train()
-        return total_tok, total_nll
+        return evaluate(self.model, self.cfg, eval_iter, self.pad_id)
+
+
+@torch.no_grad()
+def evaluate(model, cfg, eval_iter, pad_id=0):
+    """train.py:74-110 for any model: eval mode, EVALUATE lengths, same_length on; the TRAIN settings restored after.
+    Returns (non-pad target tokens, summed NLL) of this rank's share of the split."""
+    model.eval()
+    model.reset_length(tgt_len=cfg.EVALUATE.tgt_length, mem_len=cfg.EVALUATE.mem_length)
+    model.same_length = True
+    total_tok, total_nll = 0, 0.0
+    mems = None
+    for data, target, all_reset, ntok in eval_iter():
+        if all_reset:
+            mems = None
+        loss, mems = model(data, target, None, mems)
+        total_nll += ntok * float(masked_mean(loss, target, pad_id, 1.0))
+        total_tok += ntok
+    model.reset_length(cfg.TRAIN.tgt_length, cfg.TRAIN.mem_length)
+    model.same_length = cfg.MODEL.same_length
+    model.train()
+    return total_tok, total_nll
+
+
+def evaluate_best_checkpoint(path, cfg, vocab, device, eval_iter, reducer=None, pad_id=0):
+    """train.py:486-513, the script's last block: a FRESH model with `MODEL.same_length = True`, the weights of
+    `checkpoint_best.pt`, the test split through evaluate(), token count and NLL summed over the ranks (one packed
+    collective instead of the reference's two); returns (test nll per token, tokens of all ranks)."""
+    cfg = cfg.clone()
+    cfg.defrost()
+    cfg.MODEL.same_length = True
+    cfg.freeze()
+    model = MemTransformerLM(cfg, vocab)
+    model.load_state_dict(read_checkpoint(path)["model"])
+    model = model.to(device)
+    tok, nll = evaluate(model, cfg, eval_iter, pad_id)
+    if reducer is not None:
+        tok, nll = reducer.sum_scalars([tok, nll / 10000.0], device=device)
+    else:
+        tok, nll = float(tok), nll / 10000.0
+    return nll / (max(tok, 1.0) / 10000.0), int(tok)
 
 
 def save_checkpoint(path, model, optimizer, vocab, train_step, best_val_loss, scheduler):

@@ -53,7 +53,7 @@ def main(argv=None):
     from commu_amd.ddp import GradReducer
     from commu_amd.model.config_helper import get_default_cfg_training
     from commu_amd.model.dataset import ComMUDataset
-    from commu_amd.train import Trainer, build_model, save_checkpoint
+    from commu_amd.train import Trainer, build_model, evaluate_best_checkpoint, save_checkpoint
     args = parse_args(argv)
     cfg = get_default_cfg_training()
     cfg.defrost()
@@ -108,7 +108,7 @@ def main(argv=None):
     if reducer is not None:
         reducer.broadcast_params(model)                                         # DDP constructor semantics (C3)
     trainer = Trainer(model, cfg, num_gpus=num_gpus, reducer=reducer, graph=bool(getattr(args, "graph", False)),
-                      merge_chunks=getattr(args, "merge_chunks", None))
+                      merge_chunks=getattr(args, "merge_chunks", None), settle_heap=True)
     best_val_nll = float("inf")
 
     def checkpoint(name, val_nll):                                              # train.py:29-54 (C7)
@@ -150,6 +150,15 @@ def main(argv=None):
             log("-" * 100)
             log("End of training")
             break
+    # train.py:486-513: the best checkpoint, reloaded into a fresh same_length model, on the test split
+    best = os.path.join(work_dir, "checkpoint_best.pt")
+    if reducer is not None:
+        reducer.barrier()
+    if os.path.exists(best):
+        test_nll, _ = evaluate_best_checkpoint(best, cfg, dataset.vocab, device, test_iter, reducer=reducer)
+        log("=" * 100)
+        log("| End of training | test nll {:5.2f} | test ppl {:9.3f}".format(test_nll, math.exp(min(test_nll, 50.0))))
+        log("=" * 100)
     if world > 1:
         dist.destroy_process_group()
     return work_dir

@@ -261,3 +261,37 @@ def test_overlapped_exchange_is_ordered_after_its_producers(monkeypatch):
         for name, off in model_offsets.items():
             a, b = got[off[0]:off[1]], ref[off[0]:off[1]] * 0.5
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, name
+
+
+def test_hook_mode_bias_gradients_equal_the_single_stream_pass():
+    """Under an overlapped exchange (grad_ready_hook set: no column-sum group) the last layer's bias chain runs on the
+    second side stream; the colsum(dq) term of d r_r_bias must not reach the same vector from the first side stream's
+    weight-gradient reduction at the same time (round-4 advisor finding).  Repeated hook-mode passes must all equal the
+    pass with every kernel on ONE stream."""
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import build_model
+    dev = torch.device("cuda", 0)
+    cfg = _cfg_mid(16)
+    d, t, r, n = synthetic_batch(256, 16, dev, seed=78)
+
+    def grads(hook, side):
+        model = build_model(cfg, BaseVocab(), dev, seed=6)
+        model.eval()
+        model.wgrad_side_stream = side
+        model.zero_grad()
+        loss, _ = model(d, t, r, None)
+        model.grad_ready_hook = hook
+        loss.float().mean().backward()
+        model.grad_ready_hook = None
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if k in ("r_r_bias", "r_w_bias")}
+
+    def hook(G, lo, hi, evs=None):          # (orders itself after events, like GradReducer.range_ready: no blocking join)
+        return None
+    hook.wants_events = True
+    ref = grads(None, False)
+    for _ in range(5):
+        got = grads(hook, True)
+        for k in ref:
+            a, b = got[k], ref[k]
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k

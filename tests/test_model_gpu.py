@@ -419,6 +419,15 @@ def test_train_cli_runs_on_an_output_npy_directory(tmp_path):
         assert ck["train_step"] in (3, 6) and ck["amp"] is None and "optimizer" in ck
     nll = float(log.split("nll=")[1].split(",")[0])
     assert 5.0 < nll < 7.5                                  # ~ln(729) = 6.59 at initialisation
+    # train.py:486-513: the best checkpoint reloaded into a fresh same_length model and evaluated on the test split
+    # (= the validation file, dataset.py:81-86), reported in the reference's closing line
+    assert log.count("| End of training | test nll") == 1
+    tail = log.split("| End of training | test nll")[1]
+    end_nll = float(tail.split("|")[0])
+    best = read_checkpoint(os.path.join(run_dir, "checkpoint_best.pt"))
+    # the same number as the "Test step" line written when that checkpoint was saved (same weights, same split)
+    tests = [float(x.split(",")[0]) for x in log.split("test nll=")[1:]]
+    assert abs(end_nll - tests[-1]) <= 6e-3 and abs(end_nll - float(best["best_val_loss"])) <= 6e-3, (end_nll, tests, best["best_val_loss"])
 
 
 def test_generate_cli_from_a_reference_checkpoint(golden_dir, tmp_path):
