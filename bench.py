@@ -258,7 +258,7 @@ def kernel_source_hash():
     measured on (tests/probes/pmc_traffic.py stamps the same hash into the profile)."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("relattn.hip", "relattn_common.h", "common.h"):
+    for name in ("relattn.hip", "relattn3.hip", "band.hip", "gemm8.hip", "relattn_common.h", "common.h"):
         with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -286,6 +286,29 @@ def pmc_traffic(kernel, args):
     return None
 
 
+def step_traffic(args):
+    """HBM bytes one optimiser step moves, from the committed whole-step PMC passes (profiles/rNN_step_traffic.json:
+    tests/probes/step_traffic.sh -- every dispatch of the step, FETCH_SIZE x 2 + WRITE_SIZE, with a calibration line on a known
+    1 GiB copy).  None unless a profile matches the shape AND the hash of the kernel sources it was measured on."""
+    import glob
+    shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // passes_of(args)]
+    try:
+        sha = kernel_source_hash()
+    except OSError:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("shape") == shape and rec.get("source_sha256") == sha:
+            top = list(rec.get("kernels", {}).items())[:3]
+            return {"bytes": rec.get("step_hbm_bytes"), "profile": os.path.basename(path),
+                    "largest_movers": {k[:60]: round(v["bytes_per_step"] / 1e9, 3) for k, v in top}}
+    return None
+
+
 def passes_of(args):
     """Forward / backward passes per optimiser step: `batch_chunk`, or 1 when the Trainer folds the micro-batches into one
     pass (Trainer(merge_chunks=...): automatic up to Trainer.MERGE_MAX_ROWS tokens per step)."""
@@ -303,6 +326,9 @@ def auto_graph(args):
     replayed against 59.8 / 66.2 ms eager), so the default follows a work proxy: tokens per pass x layers x d_model^2
     (8 x 1024 x 6 x 512^2 = 1.3e10: graph; the headline 1.0e11, the merged default config 4.9e10, cfg-5 2.1e11: eager)."""
     return (args.batch_per_gpu // passes_of(args)) * args.tgt_len * args.layers * args.d_model ** 2 <= 2e10
+
+
+LAST_COMM = {}          # rank-local GradReducer.comm_stats() of the last train_bench (N > 1 only)
 
 
 def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
@@ -324,7 +350,7 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
         model.wgrad_side_stream = False
     if getattr(args, "fp8_forward", False):
         model.fp8_forward = True          # the layers' forward Linear products in MX-fp8 (BASELINE.json configs[4])
-    reducer = GradReducer() if world > 1 else None
+    reducer = GradReducer(wire_dtype=getattr(args, "grad_wire", "fp32")) if world > 1 else None
     if reducer is not None:
         reducer.broadcast_params(model)
     use_graph = getattr(args, "graph", None)
@@ -392,6 +418,11 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
               f"{ms['segment.all.allocated']}, retries {ms['num_alloc_retries']}", file=sys.stderr, flush=True)
         gc.callbacks.remove(_gc_cb)
     prof = _lib.profile_stop()
+    LAST_COMM.clear()
+    if reducer is not None:
+        # attribution for the scaling curve: wire bytes per rank and step, and the time the main stream sat in
+        # GradReducer.finish() waiting for the last bucket (the part of the exchange the backward pass did not hide)
+        LAST_COMM.update(reducer.comm_stats(last=steps))
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -620,6 +651,9 @@ def main():
     ap.add_argument("--merge-chunks", dest="merge_chunks", action=argparse.BooleanOptionalAction, default=None,
                     help="run the batch_chunk micro-batches of a step as one pass with per-micro-batch loss weights "
                          "(default: automatic, up to 65536 tokens per step); --no-merge-chunks: the reference's loop")
+    ap.add_argument("--grad-wire", dest="grad_wire", choices=("fp32", "bf16"), default="fp32",
+                    help="gradient exchange format of an N > 1 job: fp32 mean all-reduce (default, DDP's arithmetic) or bf16 "
+                         "on the wire with fp32 summation (all-to-all + all-gather, half the bytes)")
     ap.add_argument("--no-side-stream", action="store_true",
                     help="weight-gradient work on the main stream (default: a side stream)")
     args = ap.parse_args()
@@ -672,6 +706,21 @@ def main():
         "roofline": attention_roofline(args, prof, tokens_per_step, elapsed, pscale),
         "roofline_gemm": gemm_roofline(prof, elapsed, pscale),
     }
+    # the step's SECOND roofline: measured HBM bytes per step (PMC, committed profile) / this run's step time against the
+    # 8 TB/s peak -- the K = 512 GEMMs, LayerNorms and the attention scratch are memory-side work the MFMA fraction hides
+    st = step_traffic(args) if world == 1 else None
+    out["step_hbm_bytes"] = None if st is None else st["bytes"]
+    out["step_hbm_frac"] = (None if st is None or not st["bytes"] else
+                            round(st["bytes"] / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 4))
+    if st is not None:
+        out["step_hbm_profile"] = {"file": st["profile"], "largest_movers_GB_per_step": st["largest_movers"]}
+    if world > 1:
+        # what the exchange cost THIS rank (rank 0): bytes it put on the links per step and the un-hidden wait
+        c = dict(LAST_COMM)
+        c["exposed_share_of_step"] = (round(c["exposed_ms_per_step"] / ms_per_step, 4)
+                                      if c.get("exposed_ms_per_step") is not None else None)
+        c["payload_bytes"] = None if not c else int(c["wire_bytes_per_step"] * world / (2 * (world - 1)))
+        out["comm"] = c
     if world == 1 and (args.from_iterator or not args.no_extra):
         out["iterator_fed"] = iterator_bench(args, dev, args.steps, args.warmup, ms_per_step)
     if world == 1 and not args.no_extra:

@@ -32,7 +32,17 @@ def make_buckets(total: int, boundaries: List[int], target_elems: int) -> List[T
 class GradReducer:
     """Mean all-reduce of a flat gradient buffer in buckets."""
 
-    def __init__(self, group=None, bucket_mb: float = 16.0, exchange_single: bool = False):
+    def __init__(self, group=None, bucket_mb: float = 16.0, exchange_single: bool = False, wire_dtype: str = "fp32"):
+        """wire_dtype "fp32": one mean all-reduce per bucket on the fp32 gradient itself (58 MB per step at the bench
+        model).  "bf16" (SURVEY C4 allows a 16-bit exchange): the bucket crosses the links as bf16 but is SUMMED IN FP32 --
+        an all-to-all hands rank j the j-th shard of every rank's bucket (bf16), rank j adds the `world` shards in fp32,
+        and an all-gather returns the rounded means: 2 (N-1)/N x 2 bytes per element on the wire, half of the fp32
+        all-reduce, with one rounding of each addend and one of the result instead of a bf16 running sum inside the
+        collective; every rank ends with bit-identical gradients (they all receive the same shards).  xGMI is a full mesh
+        of point-to-point links, which is exactly what an all-to-all uses."""
+        if wire_dtype not in ("fp32", "bf16"):
+            raise ValueError("wire_dtype must be 'fp32' or 'bf16'")
+        self.wire_dtype = wire_dtype
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
@@ -43,25 +53,59 @@ class GradReducer:
         # ONE rank too -- the mean over one rank is the identity, so this only exists to execute the RCCL path on a
         # single device (tests/test_ddp_gpu.py); a one-rank job otherwise skips the exchange.
         self._active = self.world > 1 or (exchange_single and dist.is_initialized())
+        # attribution for the scaling runs: bytes each rank puts on the wire per step, and how long the main stream sat
+        # in finish() waiting for the exchange (event pairs, read back by comm_stats() after a synchronize)
+        self.wire_bytes_step = 0
+        self._exposed = []
+
+    def _wire_bytes(self, n):
+        w = max(self.world, 1)
+        return int(2 * (w - 1) / w * n * (2 if self.wire_dtype == "bf16" else 4))
+
+    def _exchange(self, t, async_op):
+        """Mean of the fp32 slice `t` over the ranks, in place; returns a handle (or None when it ran synchronously on the
+        current stream / thread)."""
+        self.wire_bytes_step += self._wire_bytes(t.numel())
+        if self.wire_dtype == "fp32":
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+        w = self.world
+        n = t.numel()
+        shard = (n + w - 1) // w
+        send = torch.zeros(w * shard, dtype=torch.bfloat16, device=t.device)
+        send[:n].copy_(t)
+        if t.is_cuda and not self._avg:
+            # gloo moves host memory only (two test ranks on one GPU): stage the bf16 shards through the host, ordered
+            # after the stream this runs on; RCCL takes the device tensors as they are
+            torch.cuda.current_stream(t.device).synchronize()
+            send = send.cpu()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        mean = (recv.view(w, shard).float().sum(0) * (1.0 / w)).to(torch.bfloat16)
+        out = torch.empty(w * shard, dtype=torch.bfloat16, device=send.device)
+        dist.all_gather_into_tensor(out, mean, group=self.group)
+        t.copy_(out[:n])
+        return None
 
     def reduce_flat(self, flat_g: torch.Tensor, boundaries: Optional[List[int]] = None):
         if not self._active:
             return
         buckets = make_buckets(flat_g.numel(), boundaries or [], self.bucket_elems)
-        avg = self._avg
-        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        self.wire_bytes_step = 0
         handles = []
         # reverse order: the backward pass finishes the LAST parameters first
         for a, b in reversed(buckets):
-            handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+            handles.append(self._exchange(flat_g[a:b], True))
         for h in handles:
-            h.wait()
-        if not avg:
+            if h is not None:
+                h.wait()
+        if self.wire_dtype == "fp32" and not self._avg:
             flat_g.mul_(1.0 / self.world)
 
     # ---- overlapped exchange (one optimiser step): begin -> range_ready* -> finish
     def begin(self):
         self._handles, self._fired, self._pending, self._events = [], [], None, []
+        self.wire_bytes_step = 0
 
     def _fire(self, flat_g, a, b):
         """Launch the all-reduce of flat_g[a:b], ordered after the pending producer events.  Device tensors: the
@@ -69,7 +113,6 @@ class GradReducer:
         backend: RCCL orders a collective after the stream it is launched from, and gloo's device-tensor path
         synchronises with that stream before staging through the host -- so neither the main stream nor the
         weight-gradient streams are ever held up by the exchange."""
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         events, self._events = self._events, []
         if flat_g.is_cuda:
             if self._stream is None:
@@ -81,9 +124,9 @@ class GradReducer:
             with torch.cuda.stream(self._stream):
                 for ev in events:
                     self._stream.wait_event(ev)
-                self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+                self._handles.append(self._exchange(flat_g[a:b], True))
         else:
-            self._handles.append(dist.all_reduce(flat_g[a:b], op=op, group=self.group, async_op=True))
+            self._handles.append(self._exchange(flat_g[a:b], True))
         self._fired.append((a, b))
 
     def range_ready(self, flat_g, lo, hi, events=None):
@@ -115,13 +158,35 @@ class GradReducer:
             if a > pos:
                 self._fire(flat_g, pos, a)
             pos = max(pos, b)
+        e0 = None
+        if flat_g.is_cuda:
+            cur = torch.cuda.current_stream(flat_g.device)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         for h in self._handles:
-            h.wait()                             # (device tensors: the CURRENT stream waits for the collective)
+            if h is not None:
+                h.wait()                         # (device tensors: the CURRENT stream waits for the collective)
         if flat_g.is_cuda and self._stream is not None:
             torch.cuda.current_stream(flat_g.device).wait_stream(self._stream)
-        if not self._avg:
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(cur)
+            self._exposed.append((e0, e1))
+            if len(self._exposed) > 4096:
+                self._exposed = self._exposed[-2048:]
+        if self.wire_dtype == "fp32" and not self._avg:
             flat_g.mul_(1.0 / self.world)
         self._handles = []
+
+    def comm_stats(self, last: Optional[int] = None):
+        """{"wire_bytes_per_step", "exposed_ms_per_step", "steps"}: bytes this rank sent per optimiser step (ring
+        all-reduce or all-to-all + all-gather volume, 2 (N-1)/N x payload) and the mean time the main stream spent in
+        finish() between arriving and being released by the last collective -- the part of the exchange the backward
+        pass did NOT hide.  Call after a device synchronize; `last`: only the most recent steps."""
+        pairs = self._exposed if last is None else self._exposed[-last:]
+        ms = [a.elapsed_time(b) for a, b in pairs]
+        return {"wire_bytes_per_step": int(self.wire_bytes_step), "wire_dtype": self.wire_dtype,
+                "exposed_ms_per_step": (sum(ms) / len(ms)) if ms else None, "steps": len(ms)}
 
     # ---- scalar reductions of the training loop (train.py:172-174, 209-210, 264-265): ONE packed all-reduce each
     def sum_scalars(self, values, device=None):

@@ -67,6 +67,24 @@ def _worker(rank, world, port, q):
         ok = ok and red.all_ok(True) and not red.all_ok(rank != 1) and not red.all_ok(False)
         cover = sorted(red2._fired)
         ok = ok and cover[0][0] == 0 and cover[-1][1] == n2 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        # bf16 WIRE FORMAT, fp32 accumulation (GradReducer(wire_dtype="bf16")): all-to-all of bf16 shards, fp32 sum on
+        # the owning rank, all-gather of the rounded means.  Expected value per element: bf16(mean of the bf16-rounded
+        # addends, summed in fp32) -- computed here the same way; both ranks must end bit-identical.
+        gen = torch.Generator().manual_seed(5)
+        base = [torch.randn(n2, generator=torch.Generator().manual_seed(100 + r)) * 0.01 for r in range(world)]
+        g3 = base[rank].clone()
+        red3 = GradReducer(bucket_mb=0.05, wire_dtype="bf16")
+        red3.begin()
+        for lo, hi in [(40_000, 49_000), (31_000, 40_000), (22_000, 31_000), (13_000, 22_000), (4_000, 13_000)]:
+            red3.range_ready(g3, lo, hi)
+        red3.finish(g3)
+        want = (sum(b.to(torch.bfloat16).float() for b in base) * (1.0 / world)).to(torch.bfloat16).float()
+        ok = ok and torch.equal(g3, want)
+        ok = ok and red3.wire_bytes_step == sum(int(2 * (world - 1) / world * (b - a) * 2) for a, b in red3._fired)
+        g4 = base[rank].clone()
+        red3.reduce_flat(g4, list(range(0, n2, 7001)))
+        ok = ok and torch.equal(g4, want)
+        ok = ok and red.wire_bytes_step > 0 and red3.comm_stats()["exposed_ms_per_step"] is None      # (CPU tensors: no events)
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -51,7 +51,8 @@ def _worker(rank, world, port, q, variant="plain"):
         torch.cuda.set_device(dev)
         cfg = _cfg(8, variant)
         model = build_model(cfg, BaseVocab(), dev, seed=5 + rank)          # different init per rank on purpose
-        red = GradReducer(bucket_mb=0.05)                                 # several buckets on this small model
+        # several buckets on this small model; "bf16_wire": the gradient crosses the ranks as bf16, summed in fp32
+        red = GradReducer(bucket_mb=0.05, wire_dtype="bf16" if variant == "bf16_wire" else "fp32")
         red.broadcast_params(model)
         tr = Trainer(model, cfg, num_gpus=world, reducer=red, graph=(variant == "graph"))
         fired, begins = [], []
@@ -73,7 +74,7 @@ def _worker(rank, world, port, q, variant="plain"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("variant", ["plain", "padded_chunk2", "graph"])
+@pytest.mark.parametrize("variant", ["plain", "padded_chunk2", "graph", "bf16_wire"])
 def test_two_rank_training_matches_single_process_with_joint_batch(variant):
     """"graph": Trainer(graph=True) on both ranks -- the step replayed from two hipGraphs with the (un-overlapped) gradient
     exchange between them, the path bench.py takes for small per-GPU batches (--global-batch 64 on 8 GPUs)."""
@@ -122,7 +123,9 @@ def test_two_rank_training_matches_single_process_with_joint_batch(variant):
     assert tok1 == log0[3] and abs(nll1 - log0[1]) < 2e-3     # token-weighted NLL of the window is rank-count invariant
     for n, p in model.named_parameters():
         a, b = p.detach().cpu(), p0[n]
-        assert torch.allclose(a, b, rtol=0, atol=3e-4), (n, float((a - b).abs().max()))
+        # (bf16 wire format: every gradient element carries two bf16 roundings, and Adam turns a relative error of a
+        #  small gradient into a step of the same relative size: looser)
+        assert torch.allclose(a, b, rtol=0, atol=2e-3 if variant == "bf16_wire" else 3e-4), (n, float((a - b).abs().max()))
 
 
 def _cfg_mid(batch):
