@@ -138,6 +138,13 @@ PROTOTYPES = {
                                      c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_copy_rows_masked_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "commu_pack_batch": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_p, c_p],
+    "commu_gemm_nt_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p],
+    "commu_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "commu_posemb_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "commu_layernorm_f32": [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "commu_relattn_f32": [c_p, c_i, c_p, c_p, C.c_longlong, C.c_longlong, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
+                          c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "commu_decode_kv_append_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "commu_hip_version": [],
 }
 _RESTYPE = {"commu_decode_tail_pack_bytes": C.c_longlong, "commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,

@@ -48,10 +48,15 @@ class DecodeState:
                                 "(the reference's 1 + 4146 fits)")
         if getattr(model, "ffn_activation", "relu") != "relu":
             raise CommuHipError("the cached decode step is built for the reference's ReLU FFN only")
-        fl = model._ensure_flat()
-        dev = fl["dev"]
         self.model, self.B, self.Lmax = model, B, Lmax
         self.attn_splits, self.split_ws, self.split_cnt = 1, None, None
+        # fp32 parity mode (model.parity_fp32, read when the state is built): fp32 weights, activations and K/V cache, the
+        # kernels of csrc/parity_f32.hip -- the mode that carries the "bit-exact greedy tokens" claim
+        self.parity = bool(getattr(model, "parity_fp32", False))
+        if self.parity:
+            return self._init_f32()
+        fl = model._ensure_flat()
+        dev = fl["dev"]
         # kernel-side dimensions (zero-padded when the model's are not multiples of 64 / 32, see model.py)
         L, D = model.n_layer, model._Dp
         H, DH = model.n_head, model._DHp
@@ -80,6 +85,68 @@ class DecodeState:
             self.t_packs = None
             self.repack()
 
+    # ---- fp32 parity mode ------------------------------------------------------------------------------------------
+    def _init_f32(self):
+        m = self.model
+        dev = next(m.parameters()).device
+        if dev.type != "cuda":
+            raise CommuHipError("the decode state lives on an MI355X (no CPU fallback)")
+        B, Lmax = self.B, self.Lmax
+        L, D, DI, H, DH, V = m.n_layer, m.d_model, m.d_inner, m.n_head, m.d_head, m.n_token
+        HD = H * DH
+        z = lambda *shape: torch.zeros(*shape, device=dev, dtype=F32)
+        self.kc, self.vc = z(L, B, Lmax, HD), z(L, B, Lmax, HD)          # [layer][sequence][position][head * d_head]
+        self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
+        self._pd = ops.posemb_f32(m.pos_emb.inv_freq, Lmax, D)
+        self.rd = [z(Lmax, HD) for _ in range(L)]
+        self.logits, self.logits_new = z(B, VPAD), z(B, VPAD)
+        self.tail_ok = False
+        self.f32 = {"h0": z(B, D), "qkv": z(B, 3 * HD), "vec": z(B, HD), "z1": z(B, D), "a": z(B, D), "hid": z(B, DI),
+                    "z2": z(B, D), "h": [z(B, D) for _ in range(L)]}
+        self.repack()
+
+    def _prefill_f32(self, ctx):
+        m = self.model
+        T0, B = ctx.shape
+        _, _, qkvs = m._run_forward_f32(ctx, None, want_kv=True)
+        HD = m.n_head * m.d_head
+        for i, qkv in enumerate(qkvs):
+            kv = qkv.view(T0, B, 3, HD)
+            self.kc[i, :, :T0].copy_(kv[:, :, 1].permute(1, 0, 2))
+            self.vc[i, :, :T0].copy_(kv[:, :, 2].permute(1, 0, 2))
+        self.klen.fill_(T0)
+
+    def _step_f32(self, tokens, active, keep, want_logits):
+        """step() on fp32 operands: per layer [qkv_net, K/V append, cached attention over the ragged memories, o_net +
+        residual, LayerNorm, FFN, LayerNorm], then the tied output layer (model.py:283-352,163-181,46).  Static buffers
+        only: capturable."""
+        m, f = self.model, self.f32
+        B, L, H, DH = self.B, m.n_layer, m.n_head, m.d_head
+        HD, V = H * DH, m.n_token
+        E = m.word_emb.emb_layers[0].weight
+        h = ops.embed_f32(tokens, E, out=f["h0"])
+        u, vb = m.r_w_bias, m.r_r_bias
+        for i in range(L):
+            lay = m.layers[i]
+            att, ff = lay.dec_attn, lay.pos_ff
+            ops.gemm_nt_f32(h, att.qkv_net.weight, out=f["qkv"])
+            ops.decode_kv_append_f32(f["qkv"], self.kc[i], self.vc[i], self.klen, active, HD, self.Lmax)
+            ops.relattn_f32(f["qkv"][:, :HD], self.kc[i], self.vc[i], HD, self.Lmax * HD, self.rd[i], u, vb, 1, 0, B, H, DH,
+                            bool(m.same_length), int(m.mem_len), m.attn_scale, klen=self.klen, out=f["vec"])
+            ops.gemm_nt_f32(f["vec"], att.o_net.weight, resid=h, out=f["z1"])
+            ops.layernorm_f32(f["z1"], att.layer_norm.weight, att.layer_norm.bias, att.layer_norm.eps, out=f["a"])
+            ops.gemm_nt_f32(f["a"], ff.CoreNet[0].weight, bias=ff.CoreNet[0].bias, relu=True, out=f["hid"])
+            ops.gemm_nt_f32(f["hid"], ff.CoreNet[3].weight, bias=ff.CoreNet[3].bias, resid=f["a"], out=f["z2"])
+            h = ops.layernorm_f32(f["z2"], ff.layer_norm.weight, ff.layer_norm.bias, ff.layer_norm.eps, out=f["h"][i])
+        if keep is not None:
+            call("commu_decode_advance", _p(self.klen), _p(keep), B, self.Lmax, _s())
+        if want_logits:
+            dst = self.logits if active is None else self.logits_new
+            ops.gemm_nt_f32(h, E, bias=m.crit.out_layers[0].bias, out=dst[:, :V])
+            if active is not None:
+                call("commu_copy_rows_masked_f32", _p(self.logits), VPAD, _p(self.logits_new), VPAD, _p(active), B, V, _s())
+        return self.logits
+
     def prefill(self, ctx: torch.Tensor):
         """ctx: int64 [T0, B] context tokens (midi_inferrer.py:186-197): fills the caches with their K/V
         (same kernels as training, memory-less forward) and sets klen = T0."""
@@ -88,6 +155,8 @@ class DecodeState:
         assert B == self.B
         if T0 >= self.Lmax:
             raise CommuHipError(f"context of {T0} tokens does not fit a decode cache of {self.Lmax} positions")
+        if self.parity:
+            return self._prefill_f32(ctx)
         _, _, qkvs = m._run_forward(ctx, None, None, None, need_grad=False, want_logits=True, want_kv=True)
         H, DH = m.n_head, m._DHp
         for i, qkv in enumerate(qkvs):
@@ -123,6 +192,8 @@ class DecodeState:
         FFN Linear 1 -> FFN Linear 2 + residual; the two LayerNorms (model.py:352,179) run INSIDE the Linear that
         consumes them (commu_gemm_nt_ln_bf16), which also stores the normalised rows for the next residual add."""
         m = self.model
+        if self.parity:
+            return self._step_f32(tokens, active, keep, want_logits)
         B, L, H, DH, D = self.B, m.n_layer, m.n_head, m._DHp, m._Dp
         if USE_LAYER_TAIL and self.tail_ok:
             return self._step_tail(tokens, active, keep, want_logits)
@@ -163,6 +234,10 @@ class DecodeState:
         layer-tail launches read (commu_decode_tail_pack): call again whenever the model's weights changed.  Everything is
         rewritten IN PLACE: a captured graph keeps pointing at the same buffers."""
         m = self.model
+        if self.parity:
+            for i in range(m.n_layer):
+                ops.gemm_nt_f32(self._pd, m.layers[i].dec_attn.r_net.weight, out=self.rd[i])
+            return
         for i in range(m.n_layer):          # the distance tables r_net(pos_emb) depend on the weights too
             ops.gemm_nt(self._pd, m._weights(i)["r"], out=self.rd[i])
         if not self.tail_ok:

@@ -61,6 +61,8 @@ class ModelInitializeTask:
         model = model.to(self.device)
         model.eval()
         model.reset_length(1, self.inference_cfg.MODEL.memory_length)
+        # generate.py --parity (not in the reference): the fp32 arithmetic of the reference instead of bf16 operands
+        model.parity_fp32 = bool(getattr(self.model_args, "parity", False))
         return model
 
     def execute(self):                                                        # :53-56

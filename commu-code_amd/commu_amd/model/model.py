@@ -223,9 +223,68 @@ class MemTransformerLM(nn.Module):
         if mems is None:
             mems = self.init_mems(self.n_layer)
         assert self.crit.n_clusters == 0
+        if getattr(self, "parity_fp32", False):          # the reference's arithmetic: fp32 end to end (see _run_forward_f32)
+            with torch.no_grad():
+                logits, new_mems, _ = self._run_forward_f32(data, mems)
+            return logits, new_mems
         with torch.no_grad():
             logits, new_mems, _ = self._run_forward(data, None, None, mems, need_grad=False, want_logits=True)
         return logits, new_mems
+
+    def _run_forward_f32(self, data, mems, want_kv=False):
+        """forward_generate (model.py:606-628 -> _forward :576-604) in the reference's own arithmetic: fp32 master weights
+        (no bf16 shadows, no padding), fp32 activations and memory, fp32 MFMA Linears, accurate transcendentals
+        (csrc/parity_f32.hip).  The mode behind the "bit-exact greedy tokens" claim: `model.parity_fp32 = True` /
+        `generate.py --parity`; what differs from the reference is summation order only.  Eval-mode semantics (no dropout),
+        memory as the reference keeps it: a fp32 [L+1, M, B, d_model] tensor."""
+        params = self._param_list()
+        dev = params[0].device
+        if dev.type != "cuda" or not data.is_cuda:
+            raise CommuHipError("MemTransformerLM runs on an MI355X only (no CPU fallback)")
+        T, B = data.shape
+        D, H, DH, L, V = self.d_model, self.n_head, self.d_head, self.n_layer, self.n_token
+        HD = H * DH
+        M = 0 if mems is None or mems.numel() == 0 else mems.shape[1]
+        if M > 0 and mems.dtype != F32:
+            mems = mems.to(F32)
+        if M > 0 and not mems.is_contiguous():
+            mems = mems.contiguous()
+        K = T + M
+        E = self.word_emb.emb_layers[0].weight
+        h = ops.embed_f32(data.contiguous().view(-1), E)                                   # model.py:585
+        pd = ops.posemb_f32(self.pos_emb.inv_freq, K, D)                                   # :578-584 (by distance)
+        u, vb = self.r_w_bias.contiguous(), self.r_r_bias.contiguous()
+        hids = [h]
+        kv_out = []
+        for i in range(L):
+            lay = self.layers[i]
+            att, ff = lay.dec_attn, lay.pos_ff
+            Wqkv = att.qkv_net.weight
+            qkv = torch.empty(K * B, 3 * HD, device=dev, dtype=F32)
+            if M > 0:                                       # memory rows: k | v only (their q third is never used, :306)
+                ops.gemm_nt_f32(mems[i].reshape(M * B, D), Wqkv[HD:], out=qkv[:M * B, HD:])
+            ops.gemm_nt_f32(h, Wqkv, out=qkv[M * B:])
+            rd = ops.gemm_nt_f32(pd, att.r_net.weight)                                     # :308-310
+            vec = ops.relattn_f32(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], B * 3 * HD, 3 * HD, rd, u, vb,
+                                  T, M, B, H, DH, bool(self.same_length), int(self.mem_len), self.attn_scale)
+            z1 = ops.gemm_nt_f32(vec, att.o_net.weight, resid=h)                           # :344-349
+            a = ops.layernorm_f32(z1, att.layer_norm.weight, att.layer_norm.bias, att.layer_norm.eps)
+            hid = ops.gemm_nt_f32(a, ff.CoreNet[0].weight, bias=ff.CoreNet[0].bias, relu=True)     # :163-181
+            z2 = ops.gemm_nt_f32(hid, ff.CoreNet[3].weight, bias=ff.CoreNet[3].bias, resid=a)
+            h = ops.layernorm_f32(z2, ff.layer_norm.weight, ff.layer_norm.bias, ff.layer_norm.eps)
+            hids.append(h)
+            if want_kv:
+                kv_out.append(qkv)
+        # K9 (model.py:507-538): cat(mems, hids)[max(0, M + T - mem_len) : M + T]
+        new_mems = None
+        if mems is not None:
+            hs = torch.stack([x.view(T, B, D) for x in hids])
+            allm = hs if M == 0 else torch.cat([mems, hs], dim=1)
+            end = M + T
+            beg = max(0, end - self.mem_len)
+            new_mems = allm[:, beg:end].contiguous()
+        logits = ops.gemm_nt_f32(h, E, bias=self.crit.out_layers[0].bias)                  # :46,620-626 (tied weight)
+        return logits.view(T, B, V), new_mems, (kv_out if want_kv else None)
 
     def zero_grad(self, set_to_none: bool = True):                      # nn.Module.zero_grad without the module-tree walk
         for p in self._param_list():

@@ -867,3 +867,81 @@ def sample_topk(logits, temperature, top_k, wrong=None, uniforms=None, active=No
          0 if wrong is None else wrong.stride(0), _p(uniforms), _p(active), float(temperature), int(top_k), float(top_p),
          _p(token), _p(probs_out), 0 if probs_out is None else probs_out.stride(0), _s())
     return token
+
+
+# ---------------------------------------------------------------------------------------------- fp32 parity mode
+# (csrc/parity_f32.hip: the generation path on fp32 operands end to end -- the reference's arithmetic, train.py:48)
+def _f32_2d(t, name):
+    if not t.is_cuda:
+        raise CommuHipError("commu_amd kernels need GPU tensors (no CPU fallback)")
+    assert t.dtype == F32 and t.dim() == 2 and t.stride(1) == 1, f"{name}: fp32 row-major 2-D tensor expected"
+    return t.stride(0)
+
+
+def gemm_nt_f32(A, B, out=None, bias=None, resid=None, relu=False):
+    """out fp32 [M, N] = A [M, K] . B [N, K]^T (+ bias) (ReLU) (+ resid): nn.Linear in fp32."""
+    lda, ldb = _f32_2d(A, "A"), _f32_2d(B, "B")
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=F32)
+    ldc = _f32_2d(out, "out")
+    assert out.shape == (M, N)
+    if bias is not None:
+        assert bias.dtype == F32 and bias.is_contiguous() and bias.numel() >= N
+    ldr = 0 if resid is None else _f32_2d(resid, "resid")
+    call("commu_gemm_nt_f32", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias), _p(resid), ldr, 1 if relu else 0, _s())
+    return out
+
+
+def embed_f32(tok, E, out=None):
+    """model.py:409-420: E[tok] * sqrt(d_model), fp32."""
+    if not tok.is_cuda:
+        raise CommuHipError("commu_amd kernels need GPU tensors (no CPU fallback)")
+    tok = tok.contiguous().view(-1)
+    assert tok.dtype == torch.long and E.dtype == F32 and E.is_contiguous()
+    rows, D = tok.numel(), E.shape[1]
+    if out is None:
+        out = torch.empty(rows, D, device=E.device, dtype=F32)
+    call("commu_embed_f32", _p(tok), _p(E), _p(out), _f32_2d(out, "out"), rows, D, math.sqrt(D), _s())
+    return out
+
+
+def posemb_f32(inv_freq, n, D, out=None):
+    """model.py:142-147 by distance: row d = [sin(d * inv_freq) | cos(d * inv_freq)]."""
+    if out is None:
+        out = torch.empty(n, D, device=inv_freq.device, dtype=F32)
+    assert inv_freq.dtype == F32 and inv_freq.numel() == D // 2
+    call("commu_posemb_f32", _p(inv_freq), _p(out), _f32_2d(out, "out"), n, D, _s())
+    return out
+
+
+def layernorm_f32(x, gamma, beta, eps=1e-5, out=None):
+    ldx = _f32_2d(x, "x")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty(rows, D, device=x.device, dtype=F32)
+    assert gamma.dtype == F32 and beta.dtype == F32 and gamma.numel() == D
+    call("commu_layernorm_f32", _p(x), ldx, _p(gamma), _p(beta), _p(out), _f32_2d(out, "out"), rows, D, float(eps), _s())
+    return out
+
+
+def relattn_f32(q, k, v, stride_key, stride_seq, rd, u, vb, T, M, B, H, DH, same_length, mem_len, scale, klen=None,
+                reset=None, out=None):
+    """model.py:283-345 in fp32 (see include/commu_hip.h, commu_relattn_f32).  q: 2-D view [T*B, >= H*DH]; k, v: tensors whose
+    data pointer is element (key 0, sequence 0, head 0, 0); rd [>= max distance + 1, >= H*DH]."""
+    ld_q = _f32_2d(q, "q")
+    ld_rd = _f32_2d(rd, "rd")
+    assert k.dtype == F32 and v.dtype == F32 and u.dtype == F32 and vb.dtype == F32
+    if out is None:
+        out = torch.empty(T * B, H * DH, device=q.device, dtype=F32)
+    call("commu_relattn_f32", _p(q), ld_q, _p(k), _p(v), int(stride_key), int(stride_seq), _p(rd), ld_rd, _p(u), _p(vb),
+         _p(klen), _p(reset), _p(out), _f32_2d(out, "out"), T, M, B, H, DH, 1 if same_length else 0, int(mem_len), float(scale),
+         _s())
+    return out
+
+
+def decode_kv_append_f32(qkv, kc, vc, klen, active, HD, Lmax):
+    call("commu_decode_kv_append_f32", _p(qkv), _f32_2d(qkv, "qkv"), _p(kc), _p(vc), _p(klen), _p(active), qkv.shape[0], HD,
+         Lmax, _s())

@@ -25,6 +25,10 @@ def parse_args():
     model_arg_parser = argparse.ArgumentParser(description="Model Arguments")
     input_arg_parser = argparse.ArgumentParser(description="Input Arguments")
     model_arg_parser.add_argument("--checkpoint_dir", type=str)
+    # not in the reference (which is fp32 throughout, train.py:48): run generation in the reference's own arithmetic --
+    # fp32 weights, activations, K/V cache and products -- instead of the bf16 throughput path.  The mode in which greedy
+    # decoding (--temperature 0) reproduces the reference's tokens without a margin condition.
+    model_arg_parser.add_argument("--parity", action="store_true")
     input_arg_parser.add_argument("--output_dir", type=str, required=True)
     input_arg_parser.add_argument("--bpm", type=int)
     input_arg_parser.add_argument("--audio_key", type=str, choices=list(meta.KEY_MAP.keys()))

@@ -475,6 +475,37 @@ int commu_decode_sample_post_pre(float* logits, int ld, int V, unsigned char* wr
 int commu_copy_rows_masked_f32(float* dst, int ldd, const float* src, int lds, const unsigned char* mask, int rows,
                                int n, hipStream_t stream);
 
+/* ---- fp32 PARITY MODE of the generation path (csrc/parity_f32.hip; model.parity_fp32 / generate.py --parity).
+ * The reference computes in fp32 throughout (train.py:48 `amp = None`; no autocast in commu/model/model.py); these entry
+ * points restate the forward pass on fp32 operands end to end -- fp32 master weights, activations and K/V cache, fp32
+ * MFMA products, accurate expf / sinf / cosf -- so that greedy decoding (midi_inferrer.py:199-237, temperature 0) picks
+ * the reference's tokens wherever the top-1 / top-2 logit gap exceeds fp32 summation-order noise (~1e-6 of the range). */
+/* nn.Linear (model.py:46,164,167,205,212,278): C[M,N] = A[M,K] . B[N,K]^T (+ bias[n]) (ReLU if relu) (+ resid[m,n]); all
+ * fp32 row-major; any M, N, K. */
+int commu_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                      const float* bias, const float* resid, int ldr, int relu, hipStream_t stream);
+/* model.py:409-420: out[row][0:D] = E[tok[row]][0:D] * scale (scale = sqrt(d_model)) */
+int commu_embed_f32(const long long* tok, const float* E, float* out, int ld, int rows, int D, float scale,
+                    hipStream_t stream);
+/* model.py:142-147 indexed by DISTANCE: out[d] = [sin(d * inv_freq) | cos(d * inv_freq)], d = 0 .. n-1 */
+int commu_posemb_f32(const float* inv_freq, float* out, int ld, int n, int D, hipStream_t stream);
+/* nn.LayerNorm (model.py:179,352), D <= 1024 */
+int commu_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows,
+                        int D, float eps, hipStream_t stream);
+/* model.py:283-345 (RelPartialLearnableMultiHeadAttn.forward without the projections), eval mode: q [T*B rows][ld_q]
+ * (row i*B+b, head h at column h*DH), element (key j, sequence b, head h, d) of k / v at base + j*stride_key +
+ * b*stride_seq + h*DH + d, rd [distance][ld_rd], out [T*B][ld_o].  klen (optional, int32 [B]): memory length of each
+ * sequence (ragged decode batch; otherwise M for all); reset (optional, uint8 [B]): hide the memory keys of that
+ * sequence; masks of model.py:549-574 with the model's mem_len.  DH <= 64. */
+int commu_relattn_f32(const float* q, int ld_q, const float* k, const float* v, long long stride_key,
+                      long long stride_seq, const float* rd, int ld_rd, const float* r_w_bias, const float* r_r_bias,
+                      const int* klen, const unsigned char* reset, float* out, int ld_o, int T, int M, int B, int H,
+                      int DH, int same_length, int mem_len, float scale, hipStream_t stream);
+/* decode step: columns [HD, 2HD) / [2HD, 3HD) of row b of the new token's projection into row klen[b] of the fp32 caches
+ * kc / vc [B][Lmax][HD], for the sequences with active[b] != 0 (null: all) */
+int commu_decode_kv_append_f32(const float* qkv, int ld, float* kc, float* vc, const int* klen,
+                               const unsigned char* active, int B, int HD, int Lmax, hipStream_t stream);
+
 /* library identification */
 const char* commu_hip_version(void);
 

@@ -18,6 +18,21 @@ def table(con, prefix):
     raise SystemExit(f"no table {prefix}* in the profile")
 
 
+def symbol(name):
+    """Demangled kernel name without namespace noise and without its argument list (template arguments kept)."""
+    s_ = name.replace("(anonymous namespace)::", "")
+    s_ = re.sub(r"^void ", "", s_)
+    depth = 0
+    for i, ch in enumerate(s_):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return s_[:i]
+    return s_
+
+
 def per_kernel(db, counter):
     """{kernel symbol: (sum of counter over its dispatches, dispatch count)}"""
     con = sqlite3.connect(db)
@@ -26,8 +41,7 @@ def per_kernel(db, counter):
             "select kernel_name, counter_name, value, dispatch_id from counters_collection"):
         if cname != counter:
             continue
-        short = re.sub(r"\(.*", "", name)          # drop the argument list of a demangled symbol
-        short = re.sub(r"^void ", "", short)
+        short = symbol(name)
         acc[short] += val
         ids[short].add(did)
     return {k: (acc[k], len(ids[k])) for k in acc}
