@@ -44,6 +44,10 @@ class ColsumTask(C.Structure):
     _fields_ = [("out", c_p), ("cols", c_i), ("src_begin", c_i), ("src_end", c_i), ("pad_", c_i)]
 
 
+class TransposeItem(C.Structure):
+    _fields_ = [("src", c_p), ("dst", c_p), ("ldi", c_i), ("ldo", c_i), ("rows", c_i), ("cols", c_i)]
+
+
 class TnProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("lda", c_i), ("ldb", c_i), ("N", c_i), ("K", c_i), ("out_off", C.c_longlong),
                 ("colsum_off", C.c_longlong)]
@@ -97,6 +101,7 @@ PROTOTYPES = {
     "commu_transpose_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_transpose_f32_bf16": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "commu_copy_bf16": [c_p, c_p, c_z, c_p],
+    "commu_transpose_group_bf16": [C.POINTER(TransposeItem), c_i, c_p],
     "commu_mems_update": [c_p, c_z, c_z, c_z, c_p, c_z, c_z, c_z, c_p, c_z, c_i, c_p],
     "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p],
     "commu_attn_p_scratch_elems": [c_i, c_i, c_i, c_i],

@@ -370,14 +370,16 @@ class MemTransformerLM(nn.Module):
         if self._padded:
             return self._refresh_padded_shadows()
 
+        pairs = []
+
         def tr(key, name, shape, pad_cols=None):
             w = self._bf16_view(name, shape)
             cols = shape[0] if pad_cols is None else pad_cols
             if key not in sh:
                 sh[key] = torch.zeros(shape[1], cols, device=dev, dtype=BF16)
-            ops.transpose_to_bf16(w, sh[key][:, :shape[0]])
+            pairs.append((w, sh[key][:, :shape[0]]))
 
-        def transposes():
+        def transposes():          # every W^T shadow of the step in ONE launch (25 launches of a few dozen workgroups before)
             tr("Et", "word_emb.emb_layers.0.weight", (V, D), VPAD)
             for i in range(self.n_layer):
                 pre = f"layers.{i}."
@@ -385,6 +387,7 @@ class MemTransformerLM(nn.Module):
                 tr(f"o_t{i}", pre + "dec_attn.o_net.weight", (D, HD))
                 tr(f"w1_t{i}", pre + "pos_ff.CoreNet.0.weight", (DI, D))
                 tr(f"w2_t{i}", pre + "pos_ff.CoreNet.3.weight", (D, DI))
+            ops.transpose_group_bf16(pairs)
         # The transposed shadows are read by the NEXT backward only (forward and decode use the plain bf16 copy): build
         # them on the side stream, beside the next forward; _run_backward waits for fl["shadow_ready"].
         if getattr(self, "wgrad_side_stream", True):
@@ -416,6 +419,7 @@ class MemTransformerLM(nn.Module):
         H, DH, DHp = self.n_head, self.d_head, self._DHp
 
         pmap = dict(self.named_parameters())
+        tpairs = []          # (padded weight, its transposed shadow): one grouped launch at the end
 
         def fp32(name):
             return pmap[name].data
@@ -428,7 +432,7 @@ class MemTransformerLM(nn.Module):
             if transpose_key is not None:
                 if transpose_key not in sh:
                     sh[transpose_key] = torch.zeros(cg * cp, rg * rp if tcols is None else tcols, device=dev, dtype=BF16)
-                ops.transpose_to_bf16(sh[key], sh[transpose_key][:, :rg * rp])
+                tpairs.append((sh[key], sh[transpose_key][:, :rg * rp]))
 
         def padv(key, name, groups, true, pad):
             if key not in sh:
@@ -446,6 +450,7 @@ class MemTransformerLM(nn.Module):
             padw(f"w2{i}", pre + "pos_ff.CoreNet.3.weight", "w2", f"w2_t{i}")
             padv(f"b1{i}", pre + "pos_ff.CoreNet.0.bias", 1, self.d_inner, self._DIp)
             padv(f"b2{i}", pre + "pos_ff.CoreNet.3.bias", 1, self.d_model, self._Dp)
+        ops.transpose_group_bf16(tpairs)
 
     # ------------------------------------------------------------------ forward schedule
     def _weights(self, i):

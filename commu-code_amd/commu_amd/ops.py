@@ -654,6 +654,22 @@ def transpose_to_bf16(x, out=None):
     return out
 
 
+def transpose_group_bf16(pairs):
+    """out[c, r] = x[r, c] for every (x, out) pair of bf16 2-D tensors, 32 pairs per launch."""
+    for i in range(0, len(pairs), 32):
+        part = pairs[i:i + 32]
+        arr = (_lib.TransposeItem * len(part))()
+        for k, (x, out) in enumerate(part):
+            if not x.is_cuda:
+                raise CommuHipError("commu_amd kernels need GPU tensors (no CPU fallback)")
+            assert x.dtype == BF16 and out.dtype == BF16 and x.stride(1) == 1 and out.stride(1) == 1
+            rows, cols = x.shape
+            assert out.shape[0] == cols and out.shape[1] >= rows
+            arr[k].src, arr[k].dst = x.data_ptr(), out.data_ptr()
+            arr[k].ldi, arr[k].ldo, arr[k].rows, arr[k].cols = x.stride(0), out.stride(0), rows, cols
+        call("commu_transpose_group_bf16", arr, len(part), _s())
+
+
 def transpose_heads(src, J, B, H, DH, W, off=0, bias=None, out=None):
     """out[b,h,f, off+j] = src[(j*B+b), h*DH+f] (+bias[h*DH+f]); other columns zero.  src is a 2-D view."""
     if out is None:

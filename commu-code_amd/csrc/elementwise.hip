@@ -1386,6 +1386,51 @@ extern "C" int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo,
     return 0;
 }
 
+// every transposed weight shadow of an optimiser step in one launch: workgroup -> (item, 64 x 64 tile) by a scan of the
+// per-item tile counts (<= 32 items: a few scalar compares)
+struct TransposeGroup {
+    commu_transpose_item it[32];
+    int tile_end[32];          // exclusive prefix of tiles
+    int n;
+};
+__global__ __launch_bounds__(256) void transpose_group_kernel(const TransposeGroup g) {
+    __shared__ bf16 t[64][66];
+    int k = 0;
+    while (k + 1 < g.n && (int)blockIdx.x >= g.tile_end[k]) ++k;
+    const commu_transpose_item& it = g.it[k];
+    const int local = (int)blockIdx.x - (k ? g.tile_end[k - 1] : 0);
+    const int tx = (it.cols + 63) / 64;
+    const int r0 = (local / tx) * 64, c0 = (local % tx) * 64;
+    const bf16* in = (const bf16*)it.in;
+    bf16* out = (bf16*)it.out;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        t[r][c] = (r0 + r < it.rows && c0 + c < it.cols) ? in[(size_t)(r0 + r) * it.ldi + c0 + c] : f2bf(0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < it.cols && r0 + r < it.rows) out[(size_t)(c0 + c) * it.ldo + r0 + r] = t[r][c];
+    }
+}
+
+extern "C" int commu_transpose_group_bf16(const commu_transpose_item* items, int n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (n > 32) return -22;
+    TransposeGroup g;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        g.it[i] = items[i];
+        if (items[i].rows <= 0 || items[i].cols <= 0) return -22;
+        total += ((items[i].rows + 63) / 64) * ((items[i].cols + 63) / 64);
+        g.tile_end[i] = total;
+    }
+    g.n = n;
+    COMMU_LAUNCH(transpose_group_kernel, dim3(total), dim3(256), 0, stream, g);
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
                                         hipStream_t stream) {
     if (rows <= 0 || cols <= 0) return 0;

@@ -208,12 +208,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     qu[ks][e] = f2bf((x + (e < 4 ? u0[e & 3] : u1[e & 3])) * c2);
                     qv[ks][e] = f2bf((x + (e < 4 ? v0[e & 3] : v1[e & 3])) * c2);
                 }
-                if (a.qu2 != nullptr && irow < T) {
-                    const size_t off = ((size_t)irow * B + b) * (a.H * 64) + h * 64 + 16 * ks + 8 * half;
-                    st_bf16x8(a.qu2 + off, qu[ks]);
-                    st_bf16x8(a.qv2 + off, qv[ks]);
-                }
             }
+            (void)irow;
         }
         f32x16 O[2];
 #pragma unroll
@@ -453,6 +449,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // epilogue: normalise, O^T through the wave's ring area as [32 rows][64] bf16 (chunk c of row r at c ^ (r & 7)),
         // out as whole 128-byte rows; lse
+        // the scaled query operands for the backward pass leave HERE, with the tile's other stores: issued in the prologue
+        // they sat in front of its `s_waitcnt vmcnt(0)`, which then also waited for eight store acknowledgements per lane
+        if (a.qu2 != nullptr && iw + ii < T) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const size_t off = ((size_t)(iw + ii) * B + b) * (a.H * 64) + h * 64 + 16 * ks + 8 * half;
+                st_bf16x8(a.qu2 + off, qu[ks]);
+                st_bf16x8(a.qv2 + off, qv[ks]);
+            }
+        }
         if (active) {
             const float l = xhalf_sum(lsA + lsB);
             const float inv = (DROP ? a.drop_scale : 1.f) / l;

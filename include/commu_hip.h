@@ -261,6 +261,15 @@ int commu_transpose_bf16(const void* in, int ldi, void* out, int ldo, int rows, 
 int commu_transpose_f32_bf16(const float* in, int ldi, void* out, int ldo, int rows, int cols,
                              hipStream_t stream);
 int commu_copy_bf16(const void* src, void* dst, size_t n, hipStream_t stream);
+/* Up to 32 bf16 transposes in ONE launch: out_i[c][r] = in_i[r][c] (the W^T shadows of every Linear weight that the
+ * dX = dY . W GEMMs read, autograd of model.py:205,212,164,167,46: 26 per optimiser step at 6 layers, each a launch of a
+ * few dozen workgroups before).  -22 for n > 32. */
+typedef struct commu_transpose_item {
+    const void* in;
+    void* out;
+    int ldi, ldo, rows, cols;
+} commu_transpose_item;
+int commu_transpose_group_bf16(const commu_transpose_item* items, int n, hipStream_t stream);
 
 /* K9  memory update (reference commu/model/model.py:507-538 _update_mems): for each of `layers` layers
  *   out[l] = [ mems[l][mem_skip : mem_skip+keep) ; hids[l][hid_skip : hid_skip+take) ]
