@@ -82,7 +82,7 @@ def cpu_baseline(args):
                       f"count comes from an earlier sweep, tests/probes/cpu_threads.py, not from this run)"}
 
 
-def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
+def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True, parity=False):
     """Second half of BASELINE.json's metric: autoregressive decode tokens/s.  The timed path is the one the
     generator ships (commu_amd.generate.ForcedDecoder): B sequences in parallel, ONE hipGraph replay per loop
     iteration = forcing decision kernel + K/V-cached decode step + temperature / top-k sampling kernel (top_k 32,
@@ -98,6 +98,9 @@ def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
     cfg = get_cfg(num_layers=args.layers, num_heads=args.heads, units=args.d_model, inner_size=args.d_inner,
                   tgt_length=1, mem_length=4146, dropout=0.0, attention_dropout=0.0, same_length=True)
     model = build_model(cfg, BaseVocab(), dev, seed=1).eval()
+    # parity: the fp32 mode of the generation path (model.parity_fp32: fp32 weights, activations, K/V cache and products --
+    # the reference's arithmetic; not the headline, reported beside it)
+    model.parity_fp32 = bool(parity)
     with torch.no_grad():
         bias = model.crit.out_layers[0].bias
         bias.zero_()
@@ -147,9 +150,10 @@ def decode_bench(dev, args, klen0, steps=1024, B=64, graph=True):
     L, D, DI = args.layers, args.d_model, args.d_inner
     kmid = klen0 + 16 + n / 2.0
     nparam = L * (4 * D * D + 2 * D * DI) + 729 * D
-    bytes_step = B * L * 2 * kmid * D * 2 + L * kmid * D * 2 + nparam * 2
+    es = 4 if parity else 2          # bytes per cached / weight element
+    bytes_step = B * L * 2 * kmid * D * es + L * kmid * D * es + nparam * es
     return {"tokens_per_s": round(B * n / dt, 1), "ms_per_step": round(1e3 * dt / n, 4), "sequences": B,
-            "klen_start": klen0, "steps": n, "hipgraph": bool(graph),
+            "klen_start": klen0, "steps": n, "hipgraph": bool(graph), "dtype": "f32" if parity else "bf16",
             "roofline": {"bound": "hbm", "achieved": round(bytes_step / (dt / n) / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(bytes_step / (dt / n) / 1e9 / HBM_PEAK_GBS, 4),
                          "bytes_per_step": int(bytes_step)}}
@@ -440,21 +444,43 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
       forward 3 products (QK^T, QR^T, PV); query-stationary backward 4 (QK^T, QR^T, dP, dQ);
       key-stationary backward 3 (dP, dV, dK: it re-reads the probabilities the query-stationary kernel stored; the
       d_head-32 variant, which recomputes QK^T and QR^T, is not on the bench path)."""
+    from commu_amd import ops
     T, M = args.tgt_len, args.mem_len
     mb_tokens = tokens_per_step // passes_of(args)
     kbar = M + (T + 1) / 2.0
-    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 4.0, "commu_relattn_bwd_kv": 3.0}
+    # forward-saved probabilities (ops.FWD_SAVES_P, kernel-side d_head 64): the query-stationary backward kernel reads the
+    # forward's probabilities instead of recomputing scores -- two products (dP, dq) instead of four, and a STREAMING kernel:
+    # it is priced against the HBM roof below
+    dh = args.d_model // args.heads
+    fromp = bool(ops.FWD_SAVES_P and ops.STORE_ATTN_P and 32 < dh <= 64)
+    products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 2.0 if fromp else 4.0, "commu_relattn_bwd_kv": 3.0}
     tot = {k: sum(v) for k, v in prof.items() if ":" not in k}
     cnt = {k: max(1, len(v)) for k, v in prof.items() if ":" not in k}
     dom = max(products, key=lambda k: tot.get(k, 0.0))
     fl_launch = mb_tokens * products[dom] * 2.0 * kbar * args.d_model
     avg_ms = tot[dom] / cnt[dom]
     achieved = fl_launch / (avg_ms * 1e-3) / 1e12
+    share = {k: round(pscale * tot[k] / (1e3 * elapsed), 4) for k in tot if tot[k] > 0}
+    if dom == "commu_relattn_bwd_q" and fromp and T % 64 == 0 and M % 64 == 0:
+        # ALGORITHMIC bytes of one launch (DESIGN.md section 4.1c; every operand and result once): the saved probabilities
+        # of the visited 64 x 64 tiles (4 tiles of 2176 bytes each), dO / K / V rows, the row statistics; written: P for the
+        # key-stationary kernel and dS by distance (2 bytes per visited score each), dq
+        Bm, H, HDk = mb_tokens // T, args.heads, args.heads * 64
+        tiles = (T // 64) * (T // 64 + 1) // 2 + (T // 64) * (M // 64)          # visited (query tile, key tile) pairs per (batch, head)
+        by = Bm * H * tiles * (4 * 2176 + 2 * 64 * 64 * 2) + (3 * T + 2 * M) * Bm * HDk * 2 + 2 * Bm * H * T * 4 + T * Bm * HDk * 2
+        gbs = by / (avg_ms * 1e-3) / 1e9
+        return {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args), "bytes_per_launch": int(by),
+                "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
+                "mfma": {"flops_per_launch": fl_launch, "achieved_tflops": round(achieved, 2),
+                         "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "products": "dP = dO.V^T and dq = dS.K"},
+                "why_hbm": "the forward pass saves its probabilities: this kernel recomputes no scores (2 of the former 4 "
+                           "products) and streams ~2 GB per launch",
+                "time_share": share, "event_sampling": "every 4th step of the timed region"}
     return {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom, args),
             "flops_per_launch": fl_launch, "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
-            "time_share": {k: round(pscale * tot[k] / (1e3 * elapsed), 4) for k in tot if tot[k] > 0},
-            "event_sampling": "every 4th step of the timed region"}
+            "time_share": share, "event_sampling": "every 4th step of the timed region"}
 
 
 def iterator_bench(args, dev, steps, warmup, resident_ms):
@@ -730,7 +756,9 @@ def main():
                                    "+ K/V-cache step + top-k 32 / T 0.95 sampling in one hipGraph per iteration)",
                          "short_memory": decode_bench(dev, args, 11), "long_memory": decode_bench(dev, args, 1000),
                          "long_memory_no_graph": decode_bench(dev, args, 1000, steps=128, graph=False),
-                         "to_completion": decode_to_completion(dev, args)}
+                         "to_completion": decode_to_completion(dev, args),
+                         # the fp32 parity mode (bit-exact greedy tokens without a margin condition): same loop, fp32 operands
+                         "short_memory_parity_fp32": decode_bench(dev, args, 11, steps=256, parity=True)}
         if not args.no_cpu_baseline:
             out["decode"]["cpu_baseline"] = decode_cpu_baseline(args)
     if world == 1 and not args.no_cpu_baseline:

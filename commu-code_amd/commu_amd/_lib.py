@@ -28,7 +28,7 @@ class AttnDesc(C.Structure):
 class AttnBwdDesc(C.Structure):
     _fields_ = [("dout", c_p), ("lse", c_p), ("delta", c_p), ("qu2", c_p), ("qv2", c_p), ("dq_ac", c_p),
                 ("dk", c_p), ("dv", c_p), ("dsk", c_p), ("du_part", c_p), ("ld_dqkv", c_i), ("ld_dsk", c_i),
-                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i), ("p_scratch", c_p), ("o", c_p)]
+                ("du_rows", c_i), ("dsk_wedge", c_i), ("dsk_tiled", c_i), ("p_scratch", c_p), ("o", c_p), ("pf", c_p)]
 
 
 class ReduceItem(C.Structure):
@@ -105,6 +105,8 @@ PROTOTYPES = {
     "commu_mems_update": [c_p, c_z, c_z, c_z, c_p, c_z, c_z, c_z, c_p, c_z, c_i, c_p],
     "commu_relattn_fwd": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p],
     "commu_attn_p_scratch_elems": [c_i, c_i, c_i, c_i],
+    "commu_relattn_fwd_save": [C.POINTER(AttnDesc), c_p, c_p, c_p, c_p, c_p, c_p],
+    "commu_attn_pf_bytes": [c_i, c_i, c_i, c_i],
     "commu_relattn_bwd": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_q": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
     "commu_relattn_bwd_kv": [C.POINTER(AttnDesc), C.POINTER(AttnBwdDesc), c_p],
@@ -152,10 +154,10 @@ PROTOTYPES = {
     "commu_decode_kv_append_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "commu_hip_version": [],
 }
-_RESTYPE = {"commu_decode_tail_pack_bytes": C.c_longlong, "commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
+_RESTYPE = {"commu_decode_tail_pack_bytes": C.c_longlong, "commu_attn_pf_bytes": C.c_longlong, "commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
             "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
 _NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_attn_fwd_generation", "commu_attn_bwd_kv_generation", "commu_colsum_slab_pass", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs",
-            "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_decode_tail_pack_bytes", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch"}
+            "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_decode_tail_pack_bytes", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch", "commu_attn_pf_bytes"}
 
 _lib = None
 

@@ -596,7 +596,8 @@ class MemTransformerLM(nn.Module):
             rd = rd_all[i] if rd_all is not None else ops.gemm_nt(pd, w["r"])    # K5
             vec, lse, qs = ops.relattn_fwd(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], rd, u, vb, rst,
                                            T, M, B, H, DH, bool(self.same_length), int(self.mem_len),
-                                           save_q=need_grad, drop_p=patt, drop_seed=ss(s0), scale=self.attn_scale)    # K6
+                                           save_q=need_grad, save_p=need_grad, drop_p=patt, drop_seed=ss(s0),
+                                           scale=self.attn_scale)    # K6
             lin = (lambda x, k, **e: ops.linear_mxfp8(x, f8[k], **e)) if fp8 else (lambda x, k, **e: ops.gemm_nt(x, w[k], **e))
             z1 = lin(vec, "o", resid=h, drop_p=p, drop_seed=ss(s0 + 1))                         # K7
             a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)

@@ -701,10 +701,17 @@ def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem
     return d
 
 
+# training forward (d_head 64): save the probabilities for the backward pass (commu_relattn_fwd_save) -- the query-stationary
+# backward kernel then recomputes neither scores, rel-shift, masks, exponentials nor the dropout hash
+import os as _os
+FWD_SAVES_P = _os.environ.get("COMMU_FWD_SAVES_P", "1") != "0"          # (the switch exists for A/B runs)
+
+
 def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None,
-                save_q=False, drop_p=0.0, drop_seed=0, scale=None):
+                save_q=False, drop_p=0.0, drop_seed=0, scale=None, save_p=False):
     """q: 2-D view [T*B, H*DH] (row stride ld_qkv), k, v: [(T+M)*B, H*DH]; rd: [K, H*DH] by distance.
-    Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], (qu2, qv2) or None)."""
+    Returns (out bf16 [T*B, H*DH], lse fp32 [B,H,T], (qu2, qv2) or None); with save_p (d_head 64, generation-3 forward)
+    the third value is (qu2, qv2, pf): pf = the forward pass's probabilities for relattn_bwd (None when not available)."""
     if out is None:
         out = torch.empty(T * B, H * DH, device=q.device, dtype=BF16)
     if lse is None:
@@ -714,6 +721,16 @@ def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
         qs = (torch.empty(T * B, H * DH, device=q.device, dtype=BF16), torch.empty(T * B, H * DH, device=q.device, dtype=BF16))
     d = _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, out.stride(0), same_length, mem_len, drop_p, drop_seed,
                    scale)
+    if save_p and qs is not None:
+        pf = None
+        if DH == 64 and FWD_SAVES_P and call("commu_attn_fwd_generation", -1) in (0, 3):
+            pf = torch.empty(call("commu_attn_pf_bytes", T, M, B, H), device=q.device, dtype=torch.uint8)
+            if POISON_SCRATCH:
+                pf.fill_(0xFF)          # (bf16 / fp32 NaN patterns: tiles the forward never writes must never be used)
+            call("commu_relattn_fwd_save", C.byref(d), _p(out), _p(lse), _p(qs[0]), _p(qs[1]), _p(pf), _s())
+            return out, lse, (qs[0], qs[1], pf)
+        call("commu_relattn_fwd", C.byref(d), _p(out), _p(lse), _p(qs[0]), _p(qs[1]), _s())
+        return out, lse, (qs[0], qs[1], None)
     call("commu_relattn_fwd", C.byref(d), _p(out), _p(lse), _p(qs[0]) if qs else None, _p(qs[1]) if qs else None, _s())
     return out, lse, qs
 
@@ -743,7 +760,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     HD = H * DH
     qrows = call("commu_attn_bwd_qrows", T)
     QT = (T + qrows - 1) // qrows
-    qu2, qv2 = qs
+    qu2, qv2 = qs[0], qs[1]
+    pf = qs[2] if len(qs) > 2 else None          # probabilities saved by the forward pass (relattn_fwd(save_p=True))
     # delta[b,h,i] = sum_d o . dout: computed (and written, for the key-stationary kernel) by the query-stationary kernel
     # from the dout fragments it holds anyway (commu_attn_bwd_desc.o); DELTA_KERNEL: the separate launch instead
     delta = torch.empty(B, H, T, device=dev, dtype=F32)
@@ -802,6 +820,8 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
             if POISON_SCRATCH:
                 pscr.fill_(float("nan"))
         e.p_scratch = pscr.data_ptr()
+        if pf is not None:
+            e.pf = pf.data_ptr()
     assert dv.stride(0) == dk.stride(0)
     if not (DELTA_KERNEL or o.stride(0) != dout.stride(0)):
         e.o = o.data_ptr()

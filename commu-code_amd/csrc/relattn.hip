@@ -750,15 +750,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // =============================================================================================
 // backward, q-stationary: dq_AC = dS.K (+ its column sums for d r_w_bias) and dS written by
 // DISTANCE (dSk[i][d = i+M-j]) for the two GEMMs  dq_BD = dSk.Rd  and  dRd = dSk^T.(q+v).
-template <int DH, int NW, bool DROP>
+// FROMP (d_head 64, four waves, a.pf from commu_relattn_fwd_save): the probabilities come from the FORWARD pass -- per key
+// tile each wave brings ONE 2176-byte tile of a.pf (32 queries x 32 keys in the forward kernel's accumulator order + the 32
+// running maxima) to LDS by LDS-DMA, double buffered, and every lane gathers its 16 values of the 16 x 64 block with
+// 2-byte LDS reads at immediate offsets from one lane address: no (q + u) . k product, no band product, no rel-shift
+// permutes, no exponential per element, no dropout hash (8 of the 26 score MFMAs and no Rd staging remain).
+template <int DH, int NW, bool DROP, bool FROMP = false>
 // (waves_per_eu(2, 2): the kernel sits at the 256-register edge; without the bound a small edit lets the compiler take a
 //  few registers more and the workgroup silently drops to one wave per SIMD -- measured 1.53 -> 1.73 ms per layer pass)
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void relattn_bwd_q_kernel(const AttnArgs a) {
+    static_assert(!FROMP || (DH == 64 && NW == 4), "forward-saved probabilities: d_head 64, 64 query rows per workgroup");
     constexpr int KS = DH / 32, DB = DH / 16;
     constexpr int QROWS = 16 * NW, NTHR = 64 * NW, NCH = NW / 4 + 1;      // query rows per workgroup, band chunks
+    constexpr int PFBUF = 4 * PF_TILE_BYTES;                              // FROMP: (2 blocks of 32 queries) x (2 sub-tiles of 32 keys)
     __shared__ __attribute__((aligned(16))) bf16 sK[64 * DH];
     __shared__ __attribute__((aligned(16))) bf16 sV[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sR[NCH * 64 * DH];
+    __shared__ __attribute__((aligned(16))) bf16 sR[FROMP ? 8 : NCH * 64 * DH];
+    __shared__ __attribute__((aligned(16))) char sPF[FROMP ? 2 * PFBUF : 16];
     __shared__ __attribute__((aligned(16))) bf16 sD[NW * 64 * PT];
     __shared__ float red[NW][DH];
     // dS-by-distance leaves through a per-wave ring [16 rows][128 distances] (row r holds distance d at column
@@ -783,10 +791,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int i0 = qt * QROWS, T = a.T, M = a.M, B = a.B, K = T + M;
     const bool rst = a.reset != nullptr && a.reset[b] != 0;
     DropLane dl_;
-    if (DROP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
+    if (DROP && !FROMP) dl_.init(salted(a.drop_seed), b, h, a.H, g, r16);
     const unsigned thr_hi = a.drop_thr << 16;
     const unsigned rsb = (unsigned)B * a.ld_qkv * 2u;
     const int HD = a.H * DH;
+    // FROMP: this wave's tile stream -- block (i0 >> 5) + (w >> 1) of the pair, sub-tile 2 jt + (w & 1) of every key tile;
+    // a block row beyond T (or a sub-tile beyond K) lies outside the descriptor and reads as zero
+    const int NS32 = (K + 31) >> 5, NB32 = (T + 31) >> 5;
+    const int pblk = (i0 >> 5) + (w >> 1);
+    const srd_t srdPF = make_srd((const char*)a.pf + (((size_t)b * a.H + h) * NB32 + (size_t)min(pblk, NB32 - 1)) * (size_t)NS32 * PF_TILE_BYTES,
+                                 (FROMP && pblk < NB32) ? (size_t)NS32 * PF_TILE_BYTES : 0);
+    const unsigned pf_lds = (unsigned)(size_t)(LDS_AS char*)sPF + (unsigned)(w * PF_TILE_BYTES);
+    // gather address of this lane (see the kernel comment): element (row 4g + reg, key 16 c + r16) of the wave's block
+    // sits at pfl + reg * 32 + (c >> 1) * PF_TILE_BYTES + (c & 1) * 16 of the tile buffer
+    const int pfl = (w >> 1) * 2 * PF_TILE_BYTES + (16 * (w & 1) + 4 * g) * 32 + 1024 * ((r16 >> 2) & 1) +
+                    (4 * (r16 >> 3) + 3 - (r16 & 3)) * 2;
+    const int mfl = (w >> 1) * 2 * PF_TILE_BYTES + 2048 + (16 * (w & 1) + 4 * g) * 4;
     // dS = P (keep dP/(1-p) - delta) scale  =  [P scale/(1-p)] (keep dP - delta (1-p)): the constant factor goes into the
     // exponent (lse2 below), delta is pre-multiplied per row -- per element: exp2, select, subtract, multiply
     const float dsc = DROP ? a.drop_scale : 1.f;
@@ -805,17 +825,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     stV.init(rsb, tid);
     stR.init((unsigned)a.ld_rd * 2u, tid);
     const unsigned rdb = (unsigned)a.ld_rd * 2u;
-    auto issue = [&](int jt) {
+    auto issue = [&](int jt, int buf) {
         const int j0 = jt * 64, dlo = i0 + M - j0 - 63;
+        if (FROMP) {
+            // (BEFORE the register-staged loads: loads return in order, so the counted wait in front of stK.store() -- the
+            //  compiler counts its own later memory operations -- also covers these three)
+            const unsigned so = (unsigned)(2 * jt + (w & 1)) * (unsigned)PF_TILE_BYTES, dst = pf_lds + (unsigned)(buf * PFBUF);
+            lds_dma16s(srdPF, (unsigned)lane * 16u, so, dst);
+            lds_dma16s(srdPF, 1024u + (unsigned)lane * 16u, so, dst + 1024u);
+            if (lane < 8) lds_dma16s(srdPF, 2048u + (unsigned)lane * 16u, so, dst + 2048u);
+        }
         stK.load(srdK, (unsigned)j0 * rsb);
         stV.load(srdV, (unsigned)j0 * rsb);
-        stR.load(srdR, (unsigned)dlo * rdb);
+        if (!FROMP) stR.load(srdR, (unsigned)dlo * rdb);
     };
-    issue(jt_lo);
+    issue(jt_lo, 0);
+    if (!FROMP) {
 #pragma unroll
-    for (int kc = 1; kc < NCH; ++kc) {      // upper chunks of the first band
-        stU[kc - 1].init((unsigned)a.ld_rd * 2u, tid);
-        stU[kc - 1].load(srdR, (unsigned)(i0 + M - jt_lo * 64 - 63 + 64 * kc) * rdb);
+        for (int kc = 1; kc < NCH; ++kc) {      // upper chunks of the first band
+            stU[kc - 1].init((unsigned)a.ld_rd * 2u, tid);
+            stU[kc - 1].load(srdR, (unsigned)(i0 + M - jt_lo * 64 - 63 + 64 * kc) * rdb);
+        }
     }
 
     bf16x8 qu[KS], qv[KS], dof[KS];
@@ -826,8 +856,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const bf16* dop = a.dout + ((size_t)iq * B + b) * a.ld_o + h * DH;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qu[ks] = ld_bf16x8(a.qu2 + off + 32 * ks + 8 * g);
-            qv[ks] = ld_bf16x8(a.qv2 + off + 32 * ks + 8 * g);
+            if (!FROMP) {
+                qu[ks] = ld_bf16x8(a.qu2 + off + 32 * ks + 8 * g);
+                qv[ks] = ld_bf16x8(a.qv2 + off + 32 * ks + 8 * g);
+            }
             dof[ks] = ld_bf16x8(dop + 32 * ks + 8 * g);
         }
         if (a.o_in != nullptr) {
@@ -881,11 +913,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     bf16* myD = sD + w * 64 * PT;
     for (int n = lane; n < 16 * SPITCH / 8; n += 64) *(bf16x8*)(myS + n * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     {
+        if (!FROMP) {
 #pragma unroll
-        for (int kc = 1; kc < NCH; ++kc) stU[kc - 1].store(sR + kc * 64 * DH);      // (chunk kc sits in slot kc at t = 0)
+            for (int kc = 1; kc < NCH; ++kc) stU[kc - 1].store(sR + kc * 64 * DH);      // (chunk kc sits in slot kc at t = 0)
+        }
         stK.store(sK);
         stV.store(sV);
-        stR.store(sR);
+        if (!FROMP) stR.store(sR);
     }
     __syncthreads();
     const int iw_lo = i0 + 16 * w, iw_hi = iw_lo + 15;
@@ -913,7 +947,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     for (int jt = jt_lo, t = 0; jt <= jt_hi; ++jt, ++t) {
         const int j0 = jt * 64;
-        if (jt < jt_hi) issue(jt + 1);
+        if (jt < jt_hi) issue(jt + 1, (t + 1) & 1);
 
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -922,37 +956,50 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             dp[c] = ndl;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s[c] = mfma16(qu[ks], ld_bf16x8(sK + 16 * c * DH + foff[ks]), s[c]);
+                if (!FROMP) s[c] = mfma16(qu[ks], ld_bf16x8(sK + 16 * c * DH + foff[ks]), s[c]);
                 dp[c] = mfma16(dof[ks], ld_bf16x8(sV + 16 * c * DH + foff[ks]), dp[c]);
             }
         }
-        f32x4 qr[5];
-#pragma unroll
-        for (int blk = 0; blk < 5; ++blk) {
-            qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const bf16* rb = sR + ring_row<NCH, NCH - 1>(16 * w + 16 * blk, t) * DH;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], ld_bf16x8(rb + foff[ks]), qr[blk]);
-        }
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            // select at the SOURCE lane t (dest lane s < row  <=>  t < row), then one permute per output
-            const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
-                        t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
-            s[0][reg] += bperm(srcaddr[reg], t0);
-            s[1][reg] += bperm(srcaddr[reg], t1);
-            s[2][reg] += bperm(srcaddr[reg], t2);
-            s[3][reg] += bperm(srcaddr[reg], t3);
-        }
         const bool need_mask = (j0 + 63 > iw_lo + M) || (a.same_length && j0 <= iw_hi - a.sshift) ||
                                (rst && j0 < M) || (iw_hi >= T);
-        if (need_mask) {
+        if (!FROMP) {
+            f32x4 qr[5];
+#pragma unroll
+            for (int blk = 0; blk < 5; ++blk) {
+                qr[blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bf16* rb = sR + ring_row<NCH, NCH - 1>(16 * w + 16 * blk, t) * DH;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qr[blk] = mfma16(qv[ks], ld_bf16x8(rb + foff[ks]), qr[blk]);
+            }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int i = iw_lo + 4 * g + reg;
+                // select at the SOURCE lane t (dest lane s < row  <=>  t < row), then one permute per output
+                const float t0 = lower[reg] ? qr[4][reg] : qr[3][reg], t1 = lower[reg] ? qr[3][reg] : qr[2][reg],
+                            t2 = lower[reg] ? qr[2][reg] : qr[1][reg], t3 = lower[reg] ? qr[1][reg] : qr[0][reg];
+                s[0][reg] += bperm(srcaddr[reg], t0);
+                s[1][reg] += bperm(srcaddr[reg], t1);
+                s[2][reg] += bperm(srcaddr[reg], t2);
+                s[3][reg] += bperm(srcaddr[reg], t3);
+            }
+            if (need_mask) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst) || i >= T) s[c][reg] = -INFINITY;
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = iw_lo + 4 * g + reg;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst) || i >= T) s[c][reg] = -INFINITY;
+                }
+            }
+        }
+        // FROMP: P scale / (1-p) = |e| * exp2(m + nls) with e, m from the forward pass; eight factors per lane and tile
+        const LDS_AS char* pfb = (const LDS_AS char*)sPF + (t & 1) * PFBUF;
+        f32x4 fac[2];
+        if (FROMP) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const f32x4 mv = *(const LDS_AS f32x4*)(pfb + mfl + sub * PF_TILE_BYTES);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) fac[sub][reg] = __builtin_amdgcn_exp2f(mv[reg] + nls[reg]);
             }
         }
         // dS = P (dP - delta) scale
@@ -963,15 +1010,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int c = 0; c < 4; ++c) {
             bf16x4 db;
             unsigned hw[4] = {0u, 0u, 0u, 0u};
-            if (DROP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
+            if (DROP && !FROMP) dl_.words(iw_lo >> 4, (j0 >> 4) + c, hw);
             bf16x4 pq;
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float p = __builtin_amdgcn_exp2f(s[c][reg]);          // P * scale / (1-p)
+                float p;          // P * scale / (1-p)
+                bool keep;
+                if (FROMP) {
+                    const unsigned raw = *(const LDS_AS unsigned short*)(pfb + pfl + reg * 32 + (c >> 1) * PF_TILE_BYTES + (c & 1) * 16);
+                    keep = (raw & 0x8000u) == 0u;
+                    p = __builtin_bit_cast(float, (raw & 0x7FFFu) << 16) * fac[c >> 1][reg];
+                    // (tiles the forward pass never wrote -- beyond the causal edge of a 32-row block -- hold anything: select)
+                    if (need_mask) {
+                        const int i = iw_lo + 4 * g + reg;
+                        if (is_masked(i, j0 + 16 * c + r16, M, a.same_length, a.sshift, rst) || i >= T) p = 0.f;
+                    }
+                } else {
+                    p = __builtin_amdgcn_exp2f(s[c][reg]);
+                    keep = !DROP || drop_keep16(hw, reg, a.drop_thr, thr_hi);
+                }
                 float dpe = dp[c][reg];                                       // dP - delta (1-p)
                 float ps = p;
                 if (DROP) {
-                    const bool keep = drop_keep16(hw, reg, a.drop_thr, thr_hi);
                     dpe = keep ? dpe : ndl[reg];
                     ps = keep ? p : -p;          // the stored probability carries the keep decision in its sign: the
                 }                                // key-stationary kernel does not hash again
@@ -1019,7 +1079,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (jt < jt_hi) {
             stK.store(sK);
             stV.store(sV);
-            stR.store(sR + ((((NCH - 1) * (t + 1)) % NCH) << 6) * DH);
+            if (!FROMP) stR.store(sR + ((((NCH - 1) * (t + 1)) % NCH) << 6) * DH);
         }
         __syncthreads();
     }
@@ -1528,13 +1588,34 @@ extern "C" int commu_attn_fwd_generation(int gen) {
     return prev;
 }
 
+extern "C" long long commu_attn_pf_bytes(int T, int M, int B, int H) {
+    return (long long)B * H * ((T + 31) / 32) * ((T + M + 31) / 32) * PF_TILE_BYTES;
+}
+
+static int relattn_fwd_impl(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2, void* pf, hipStream_t stream);
+
 extern "C" int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                                  hipStream_t stream) {
+    return relattn_fwd_impl(d, out, lse, qu2, qv2, nullptr, stream);
+}
+
+extern "C" int commu_relattn_fwd_save(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2, void* pf,
+                                      hipStream_t stream) {
+    // (the tiles of one 32-query block are addressed through one buffer descriptor: 32-bit offsets)
+    if (pf == nullptr || d->DH != 64 || (g_fwd_gen != 0 && g_fwd_gen != 3) ||
+        (long long)((d->T + d->M + 31) / 32) * PF_TILE_BYTES >= 0x7FFF0000ll)
+        return -22;
+    return relattn_fwd_impl(d, out, lse, qu2, qv2, pf, stream);
+}
+
+static int relattn_fwd_impl(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2, void* pf,
+                            hipStream_t stream) {
     if (d->T <= 0 || d->B <= 0) return 0;
     if ((d->ld_qkv % 8) || (d->ld_rd % 8) || !fits_srd(d) || ((qu2 == nullptr) != (qv2 == nullptr))) return -22;
     AttnArgs a = {};
     fill_common(a, d);
     a.out = (bf16*)out; a.lse = lse; a.qu2 = (bf16*)qu2; a.qv2 = (bf16*)qv2;
+    a.pf = pf;
     // (the kernels are parametrised by waves per workgroup; 8-wave / 128-row tiles measured slower than 4-wave
     // tiles at every shape of this model, so only NW = 4 is instantiated)
     dim3 grid((((d->T + 63) / 64 + 1) / 2) * d->H * d->B);
@@ -1588,6 +1669,8 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     a.dsk_tiled = e->dsk_tiled;
     a.pbuf = (bf16*)e->p_scratch;
     a.o_in = (const bf16*)e->o;
+    a.pf = const_cast<void*>(e->pf);
+    if (e->pf != nullptr && (e->p_scratch == nullptr || d->DH != 64)) return -22;
     if (e->p_scratch != nullptr && d->DH != 64) return -22;
     if (a.dsk_wedge > 0 && d->same_length) return -22;
     if ((e->ld_dsk % 8) || (a.dsk_tiled && ((e->ld_dsk % 128) || (((long long)d->T * d->B) % 64)))) return -22;
@@ -1600,11 +1683,14 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
         //  backward pass must see the same setting -- it fixes the block order of the P scratch)
         const bool kv3 = KV3_DEFAULT ? g_kv_gen != 2 : g_kv_gen == 3;
         a.p_layout = kv3 ? 1 : 0;
+        const bool fromp = a.pf != nullptr;          // probabilities saved by the forward pass: no score recomputation
         if (drop) {
-            if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, true>), gq, dim3(256), 0, stream, a);
+            if ((which & 1) && fromp) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, true, true>), gq, dim3(256), 0, stream, a);
+            if ((which & 1) && !fromp) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, true>), gq, dim3(256), 0, stream, a);
             if ((which & 2) && !kv3) COMMU_LAUNCH((relattn_bwd_kv2_kernel<true>), gk, dim3(256), 0, stream, a);
         } else {
-            if (which & 1) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, false>), gq, dim3(256), 0, stream, a);
+            if ((which & 1) && fromp) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, false, true>), gq, dim3(256), 0, stream, a);
+            if ((which & 1) && !fromp) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, false>), gq, dim3(256), 0, stream, a);
             if ((which & 2) && !kv3) COMMU_LAUNCH((relattn_bwd_kv2_kernel<false>), gk, dim3(256), 0, stream, a);
         }
         if ((which & 2) && kv3) launch_relattn_bwd_kv3(a, stream);

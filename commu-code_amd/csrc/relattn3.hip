@@ -78,7 +78,8 @@ constexpr unsigned DROP_CM[2][2] = {{0x9E3779u, 0x85EBCBu}, {0xC2B2AFu, 0xB5297B
 constexpr unsigned DROP_KA[2][2] = {{0x85EBCA6Bu, 0xC2B2AE35u}, {0x27D4EB2Fu, 0x165667B1u}};
 constexpr unsigned DROP_KB[2][2] = {{0x6A09E667u, 0xBB67AE85u}, {0x3C6EF372u, 0xA54FF53Au}};
 
-template <bool DROP>
+// SAVEP: the probabilities also go to a.pf for the backward pass (commu_relattn_fwd_save; see relattn_common.h)
+template <bool DROP, bool SAVEP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void relattn_fwd3_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(1024))) char smem[LDS_FWD3];
     const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
@@ -211,6 +212,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             (void)irow;
         }
+        // probabilities for the backward pass (a.pf, see relattn_common.h): this wave's row of 2176-byte tiles, one per
+        // 32-key sub-tile; an inactive wave or a forward-only call stores through an empty descriptor (dropped)
+        const int NS32 = (K + 31) >> 5;
+        const size_t pfrow = (((size_t)b * a.H + h) * (size_t)((T + 31) >> 5) + (size_t)(iw >> 5)) * (size_t)NS32;
+        const srd_t srdPF = make_srd((const char*)a.pf + (SAVEP ? pfrow * PF_TILE_BYTES : 0),
+                                     (SAVEP && active) ? (size_t)NS32 * PF_TILE_BYTES : 0);
         f32x16 O[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -316,6 +323,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 k3 = iodd ? k1 * DROP_KA[1][1] + DROP_KB[1][1] : k1 * DROP_KA[0][1] + DROP_KB[0][1];
             }
             unsigned pw[8];
+            unsigned ps[4];                                       // (DROP) signed copies for a.pf, four at a time
+            const unsigned psoff = (unsigned)(2 * jt_lo + n) * (unsigned)PF_TILE_BYTES;
+            // the running maximum this sub-tile is exponentiated against (constant over the step): the tile's last 128 bytes
+            // (lanes of half 1 aim out of range: dropped)
+            if (SAVEP)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mrow), srdPF,
+                                                      half == 0 ? 2048 + ii * 4 : (int)0x80000000u, (int)psoff, 0);
             auto sm = [&](int k) {                                // keys 2k, 2k+1 of the quad layout: exp, sums, dropout, bf16 pair
                 float e0 = __builtin_amdgcn_exp2f(Sc[2 * k] - mrow), e1 = __builtin_amdgcn_exp2f(Sc[2 * k + 1] - mrow);
                 lsA += e0;                                        // the normaliser is the un-dropped sum
@@ -326,11 +340,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     unsigned y = xl + ((unsigned)(4 * (k >> 1) + 1 - (k & 1)) * DROP_C1 + k1);
                     y ^= y >> 12;
                     const unsigned w0 = (y & 0xFFFFFFu) * cme + k2, w1 = (y & 0xFFFFFFu) * cmo + k3;
+                    // saved for the backward pass BEFORE the mask is applied: a dropped probability keeps its value (dS needs
+                    // it) and carries the decision in its sign
+                    if (SAVEP)
+                        ps[k & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                            (f32x2){w1 >= thr32 ? e0 : -e0, w0 >= thr32 ? e1 : -e1}, bf16x2));
                     e0 = w1 >= thr32 ? e0 : 0.f;
                     e1 = w0 >= thr32 ? e1 : 0.f;
                 }
                 // (the compiler's own v_cvt_pk_bf16_f32: it knows the wait state a transcendental result needs)
                 pw[k] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){e0, e1}, bf16x2));
+                if (SAVEP && (k & 3) == 3) {                      // registers 8 (k >> 2) .. + 7 of the lane: 16 of its 32 bytes
+                    const u32x4 v4 = DROP ? (u32x4){ps[0], ps[1], ps[2], ps[3]} : (u32x4){pw[k - 3], pw[k - 2], pw[k - 1], pw[k]};
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, srdPF, lane * 32 + 16 * (k >> 2), (int)psoff, 0);
+                }
             };
             bf16x4 vt[2][2][2];                                   // [ks2][dt][X]
             auto vread = [&](int dt) {
@@ -487,8 +510,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int launch_relattn_fwd3(const AttnArgs& a, hipStream_t stream) {
     const int QT = (a.T + 255) / 256;
     dim3 grid(((QT + 1) / 2) * a.H * a.B);
-    if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_fwd3_kernel<true>), grid, dim3(512), 0, stream, a);
-    else COMMU_LAUNCH((relattn_fwd3_kernel<false>), grid, dim3(512), 0, stream, a);
+    if (a.pf != nullptr) {
+        if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_fwd3_kernel<true, true>), grid, dim3(512), 0, stream, a);
+        else COMMU_LAUNCH((relattn_fwd3_kernel<false, true>), grid, dim3(512), 0, stream, a);
+    } else {
+        if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_fwd3_kernel<true, false>), grid, dim3(512), 0, stream, a);
+        else COMMU_LAUNCH((relattn_fwd3_kernel<false, false>), grid, dim3(512), 0, stream, a);
+    }
     COMMU_LAUNCH_CHECK();
     return 0;
 }

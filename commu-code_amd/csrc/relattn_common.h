@@ -27,6 +27,13 @@ struct AttnArgs {
     bf16* dsk;          // [H][T*B][ld_dsk]  dS indexed by distance d (zero-initialised by the caller)
     float* du_part;     // [B*QT][H*DH] column sums of dq (AC part)
     bf16* pbuf;         // P scratch [B*H][ceil(T/16)][ceil(K/64)][64 keys][16 rows]: written by bwd_q, read by bwd_kv2 (or null)
+    // Probabilities saved by the FORWARD pass (relattn_fwd3 writes, relattn_bwd_q<.., FROMP> reads; null: the backward
+    // recomputes its scores): pf = [B*H][ceil(T/32)][ceil(K/32)] tiles of PF_TILE_BYTES.  Bytes 0 .. 2047 of a tile are the
+    // forward kernel's accumulator order -- lane (query i & 31, key half (jj >> 2) & 1) holds 16 bf16, register r = key
+    // jj = 8 (r >> 2) + 4 half + 3 - (r & 3) of the 32-key sub-tile -- of e = exp2(s - m), m = the row's RUNNING maximum when
+    // that sub-tile was exponentiated (log2 domain), sign bit = dropped by the attention dropout; bytes 2048 .. 2175 are
+    // that m for the 32 queries (fp32).  P = |e| * exp2(m - lse * log2 e).
+    void* pf;
     int p_layout;       // 0: the block order above; 1: [B*H][ceil(T/32)][2 ceil(K/64)] blocks of [32 keys][2 halves][4][4 queries],
                         //    the accumulator order of relattn_bwd_kv3_kernel
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
@@ -43,6 +50,8 @@ struct AttnArgs {
 int launch_relattn_fwd3(const AttnArgs& a, hipStream_t stream);
 // relattn_kv3.hip (d_head 64): key-stationary backward from stored probabilities (p_layout 1) on the same MFMA
 int launch_relattn_bwd_kv3(const AttnArgs& a, hipStream_t stream);
+
+constexpr int PF_TILE_BYTES = 2176;
 
 namespace {
 
@@ -93,6 +102,11 @@ __device__ __forceinline__ void tile_coords(int ntile, int H, int B, int& tile, 
 __device__ __forceinline__ void lds_dma16(srd_t srd, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :: "s"(lds_dst), "v"(voff), "s"(srd) : "memory");
+}
+// (tile offset in the scalar operand: one descriptor per stream of tiles)
+__device__ __forceinline__ void lds_dma16s(srd_t srd, unsigned voff, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;

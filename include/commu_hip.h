@@ -302,6 +302,15 @@ typedef struct commu_attn_desc {
  * backward kernels re-use. */
 int commu_relattn_fwd(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2,
                       hipStream_t stream);
+/* The same forward pass, additionally SAVING its probabilities for the backward pass (d_head 64, generation-3 forward
+ * only; -22 otherwise): pf = commu_attn_pf_bytes(T, M, B, H) bytes, uninitialised -- per (batch, head, 32-query block,
+ * 32-key sub-tile the forward visits) a 2176-byte tile: exp2(s - m) as bf16 in the forward kernel's accumulator order,
+ * m = the query's running maximum at that sub-tile, the dropout decision in the sign bit, then the 32 values of m.
+ * commu_attn_bwd_desc.pf hands it to the query-stationary backward kernel, which then neither recomputes
+ * (q + u) . k, the band product / rel-shift, the masks, exp nor the dropout hash (autograd of model.py:313-345). */
+int commu_relattn_fwd_save(const commu_attn_desc* d, void* out, float* lse, void* qu2, void* qv2, void* pf,
+                           hipStream_t stream);
+long long commu_attn_pf_bytes(int T, int M, int B, int H);
 /* Forward kernel generation for d_head 64 (process-wide; returns the previous value).  0 (default) and 3: the 32x32-MFMA /
  * transposed-score kernel (relattn3.hip), with or without attention dropout; 2: the 16x16-layout kernel.  Every attention
  * kernel -- both forward generations and the backward family -- regenerates the same dropout mask (relattn.hip DropLane: one
@@ -346,6 +355,7 @@ typedef struct commu_attn_bwd_desc {
     const void* o;        /* NULL, or the forward output (bf16 [T*B][ld_o]): the query-stationary kernel then computes
                              delta[b,h,i] = sum_d o . dout itself (commu_attn_delta is not needed) and WRITES it to
                              `delta` for the key-stationary kernel, which must run after it on the same stream */
+    const void* pf;       /* NULL, or the buffer commu_relattn_fwd_save filled for this call (needs p_scratch, d_head 64) */
 } commu_attn_bwd_desc;
 long long commu_attn_p_scratch_elems(int T, int M, int B, int H);
 int commu_attn_bwd_qrows(int T);

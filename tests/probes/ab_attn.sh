@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 out = []
 for r in rows:
     n = r['Name']
-    for key in ("relattn_bwd_q", "relattn_bwd_kv2", "relattn_fwd2", "band_bwd"):
+    for key in ("relattn_bwd_q", "relattn_bwd_kv2", "relattn_fwd3", "band_bwd"):
         if key in n: out.append(f"{key} {float(r['AverageNs'])/1e3:.1f}")
 print(sys.argv[2], " | ".join(out))
 PY

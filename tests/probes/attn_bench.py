@@ -17,6 +17,7 @@ H, DH = 8, 64
 REPS = int(os.environ.get("AB_REPS", 3))
 WHAT = os.environ.get("AB_WHAT", "fwd,bwd")
 DROP = float(os.environ.get("AB_DROP", 0.0))
+ops.FWD_SAVES_P = os.environ.get("AB_SAVEP", "1") != "0"          # forward-saved probabilities (the training path)
 dev = "cuda"
 K = T + M
 HD = H * DH
@@ -33,7 +34,7 @@ du, dvb = torch.zeros(HD, device=dev), torch.zeros(HD, device=dev)
 
 
 def run():
-    out, lse, qs = ops.relattn_fwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, save_q=True, drop_p=DROP, drop_seed=1234)
+    out, lse, qs = ops.relattn_fwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, save_q=True, save_p=True, drop_p=DROP, drop_seed=1234)
     if "bwd" in WHAT:
         ops.relattn_bwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, out, dout, lse, qs, dqkv[M * B:, :HD],
                         dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=DROP, drop_seed=1234)

@@ -30,7 +30,7 @@ def per_launch(db, counter):
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sha = hashlib.sha256()
-for name in ("relattn.hip", "relattn_common.h", "common.h"):          # the same hash bench.py computes: a stale profile is refused
+for name in ("relattn.hip", "relattn3.hip", "band.hip", "gemm8.hip", "relattn_common.h", "common.h"):          # the same hash bench.py computes: a stale profile is refused
     with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
         sha.update(f.read())
 out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": sha.hexdigest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "

@@ -103,18 +103,22 @@ def attn_keep(seed, B, H, T, K, p):
 
 
 @pytest.mark.parametrize("fwd_gen", [0, 2], ids=["fwd_default", "fwd_16x16"])
-@pytest.mark.parametrize("store_p", [False, True, 3], ids=["recompute", "stored_p", "stored_p_kv3"])
+@pytest.mark.parametrize("store_p", [False, True, 3, "fwd_p"], ids=["recompute", "stored_p", "stored_p_kv3", "forward_p"])
 @pytest.mark.parametrize("case", [(64, 0, 2, 2, 64), (40, 24, 2, 2, 32), (130, 0, 1, 1, 64), (200, 70, 3, 2, 64)])
 def test_attention_dropout_fwd_bwd_exact_mask(case, store_p, fwd_gen):
     """Forward and backward regenerate ONE mask (ops.attn_dropout_keep_mask): the default forward of d_head 64 is the
     transposed 32x32 kernel (relattn3.hip), the backward kernels are the 16x16 family -- different register layouts, the
-    same keep decisions; fwd_16x16 forces the older forward."""
+    same keep decisions; fwd_16x16 forces the older forward.  forward_p (the training path): the forward saves its
+    probabilities with the keep decision in the sign bit and the query-stationary backward kernel takes both from there."""
     from commu_amd import ops
     T, M, B, H, DH = case
+    fwd_p = store_p == "fwd_p"
+    if fwd_p:
+        store_p = True
     if store_p and DH != 64:
         pytest.skip("stored probabilities: d_head 64 kernels only")
-    if fwd_gen == 2 and DH != 64:
-        pytest.skip("one forward kernel for this d_head")
+    if fwd_gen == 2 and (DH != 64 or fwd_p):
+        pytest.skip("one forward kernel for this d_head / the 16x16 forward does not save probabilities")
     K, HD, p, seed = T + M, H * DH, 0.2, 424243
     g = torch.Generator().manual_seed(3)
     qkv = bf(torch.randn(K * B, 3 * HD, generator=g) * 0.7)
@@ -134,11 +138,14 @@ def test_attention_dropout_fwd_bwd_exact_mask(case, store_p, fwd_gen):
     gq = qkv.to(DEV)
     q, k, v = gq[M * B:, :HD], gq[:, HD:2 * HD], gq[:, 2 * HD:]
     prev_gen = ops.attn_fwd_generation(fwd_gen)
+    keep_save, ops.FWD_SAVES_P = ops.FWD_SAVES_P, fwd_p
     try:
         out, lse, qs = ops.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), None, T, M, B, H, DH, False, M,
-                                       save_q=True, drop_p=p, drop_seed=seed)
+                                       save_q=True, save_p=True, drop_p=p, drop_seed=seed)
     finally:
         ops.attn_fwd_generation(prev_gen)
+        ops.FWD_SAVES_P = keep_save
+    assert (qs[2] is not None) == fwd_p
     assert relerr(out, ref) < 1.5e-2
     dqkv = torch.zeros_like(gq)
     drd = torch.zeros(K, HD, device=DEV)

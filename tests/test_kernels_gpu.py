@@ -686,14 +686,20 @@ def test_relattn_bwd_delta_inside_the_query_kernel():
         assert relerr(b_, a_) < 2e-3
 
 
-@pytest.mark.parametrize("store_p", [False, True, 3], ids=["recompute", "stored_p", "stored_p_kv3"])
+@pytest.mark.parametrize("store_p", [False, True, 3, "fwd_p", "fwd_p_kv3"],
+                         ids=["recompute", "stored_p", "stored_p_kv3", "forward_p", "forward_p_kv3"])
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_relattn_bwd(case, store_p):
     """store_p: the query-stationary kernel writes the probabilities it recomputes into a scratch buffer (poisoned with
     NaN here) and the key-stationary kernel reads them back (d_head 64); otherwise both recompute P from (q+u).k, the
-    band product and lse.  Both against autograd of the oracle."""
+    band product and lse.  forward_p: the FORWARD pass saved its probabilities (commu_relattn_fwd_save, buffer poisoned
+    before the call: tiles the forward never visits hold NaN patterns) and the query-stationary kernel reads them instead of
+    recomputing scores -- the training path for d_head 64.  All against autograd of the oracle."""
     o = ops()
     T, M, B, H, DH, sl, mem_len, rc = case
+    fwd_p = isinstance(store_p, str)
+    if fwd_p:
+        store_p = 3 if store_p.endswith("kv3") else True
     if store_p and DH != 64:
         pytest.skip("stored probabilities: d_head 64 kernels only")
     K = T + M
@@ -716,9 +722,14 @@ def test_relattn_bwd(case, store_p):
     dqkv = torch.zeros_like(g)
     drd = torch.zeros(K, HD, device=DEV)
     du, dvb = torch.zeros(HD, device=DEV), torch.zeros(HD, device=DEV)
-    out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len,
-                                 save_q=True)
     o.POISON_SCRATCH = True           # NaN in every scratch element the kernels are not supposed to read
+    keep_save, o.FWD_SAVES_P = o.FWD_SAVES_P, fwd_p
+    try:
+        out, lse, qs = o.relattn_fwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len,
+                                     save_q=True, save_p=True)
+    finally:
+        o.FWD_SAVES_P = keep_save
+    assert (qs[2] is not None) == fwd_p
     keep_flag, o.STORE_ATTN_P = o.STORE_ATTN_P, bool(store_p)
     # (stored_p_kv3: the key-stationary kernel of relattn_kv3.hip -- 32 keys per wave on the 32x32 MFMA -- and the block order
     #  of the scratch that goes with it; stored_p: the 16x16-layout kernel)
