@@ -403,7 +403,7 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    prof_names = ["commu_relattn_bwd_kv", "commu_relattn_bwd_q", "commu_relattn_fwd", "commu_gemm_nt_bf16",
+    prof_names = ["commu_relattn_bwd_kv", "commu_relattn_bwd_q", "commu_relattn_fwd", "commu_relattn_fwd_save", "commu_gemm_nt_bf16",
                   "commu_gemm_tn_bf16", "commu_gemm_tn_bf16_grouped", "commu_relattn_bwd_band"]
     # (an event pair around every profiled call costs ~4 % of a step -- ~130 calls -- so only every fourth step of the
     #  timed region is instrumented; time_share scales the sampled sums back to the whole region)
@@ -454,6 +454,8 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
     dh = args.d_model // args.heads
     fromp = bool(ops.FWD_SAVES_P and ops.STORE_ATTN_P and 32 < dh <= 64)
     products = {"commu_relattn_fwd": 3.0, "commu_relattn_bwd_q": 2.0 if fromp else 4.0, "commu_relattn_bwd_kv": 3.0}
+    prof = dict(prof)          # (the training forward goes through the entry point that also saves its probabilities)
+    prof["commu_relattn_fwd"] = list(prof.get("commu_relattn_fwd", [])) + list(prof.pop("commu_relattn_fwd_save", []))
     tot = {k: sum(v) for k, v in prof.items() if ":" not in k}
     cnt = {k: max(1, len(v)) for k, v in prof.items() if ":" not in k}
     dom = max(products, key=lambda k: tot.get(k, 0.0))

@@ -701,10 +701,16 @@ def _attn_desc(q, k, v, rd, u, vb, reset, T, M, B, H, DH, ld_o, same_length, mem
     return d
 
 
-# training forward (d_head 64): save the probabilities for the backward pass (commu_relattn_fwd_save) -- the query-stationary
-# backward kernel then recomputes neither scores, rel-shift, masks, exponentials nor the dropout hash
+# Training forward (d_head 64) that SAVES its probabilities for the backward pass (commu_relattn_fwd_save): the
+# query-stationary backward kernel then recomputes neither scores, rel-shift, masks, exponentials nor the dropout hash (2 of
+# its 4 products remain).  Built, tested (tests/test_kernels_gpu.py "forward_p") and OFF by default: on MI355X the step is
+# bound by memory traffic, and the trade buys compute with bytes -- relattn_bwd_q 690 -> 645 us, relattn_fwd3 297 -> 358 us
+# (+0.59 GB of stores per launch through a store path that is already the forward's second-largest cost), the step within
+# +-1 % (16.48 -> 16.36 ms on one box), +6.8 GB of HBM traffic and +6.4 GB of live memory per step.  Feeding the
+# key-stationary kernel from the same tiles (so that no kernel stores P) was built too: that kernel 292 -> 387 us, the step
+# 15.80 -> 16.10 ms.  DESIGN.md section 8e.
 import os as _os
-FWD_SAVES_P = _os.environ.get("COMMU_FWD_SAVES_P", "1") != "0"          # (the switch exists for A/B runs)
+FWD_SAVES_P = _os.environ.get("COMMU_FWD_SAVES_P", "0") == "1"
 
 
 def relattn_fwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len, out=None, lse=None,

@@ -16,7 +16,7 @@ for r in rows:
     n = r['Name']
     for key in ("relattn_bwd_q", "relattn_bwd_kv2", "relattn_fwd3", "band_bwd"):
         if key in n: out.append(f"{key} {float(r['AverageNs'])/1e3:.1f}")
-print(sys.argv[2], " | ".join(out))
+print(sys.argv[2], " | ".join(sorted(out)))
 PY
 done
 cp $L/libcommu_hip_new.so $L/libcommu_hip.so

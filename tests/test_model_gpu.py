@@ -502,6 +502,42 @@ def test_relu_sign_bits_option_gives_identical_gradients(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_forward_saved_probabilities_option_gives_the_same_step(monkeypatch):
+    """ops.FWD_SAVES_P (opt-in): the training forward of d_head 64 saves its probabilities and the query-stationary
+    backward kernel reads them instead of recomputing scores.  Two segments with XL memory, reset columns and dropout on
+    (same seeds): the loss is identical (same forward arithmetic) and every gradient agrees with the default path to the
+    bf16 rounding of one more intermediate (the saved probability)."""
+    from commu_amd import ops
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import build_model
+    dev = torch.device("cuda", 0)
+    cfg = get_cfg(num_layers=2, num_heads=2, units=128, inner_size=256, tgt_length=96, mem_length=64, batch_size=6,
+                  batch_chunk=1, dropout=0.1, attention_dropout=0.1)
+    segs = [synthetic_batch(96, 6, dev, seed=30 + i, reset_prob=0.3) for i in range(2)]
+    out = []
+    for flag in (False, True):
+        monkeypatch.setattr(ops, "FWD_SAVES_P", flag)
+        model = build_model(cfg, BaseVocab(), dev, seed=5)
+        model.train()
+        model.fixed_drop_seed = 4242
+        mems, losses = None, []
+        model.zero_grad()
+        for d, t, r, _ in segs:
+            loss, mems = model(d, t, r, mems)
+            loss.float().mean().backward()
+            losses.append(loss.detach().clone())
+        out.append((losses, {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    for la, lb in zip(out[0][0], out[1][0]):
+        assert torch.equal(la, lb)
+    for n in out[0][1]:
+        ga, gb = out[0][1][n].float(), out[1][1][n].float()
+        cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
+        assert cos > 0.9995, (n, cos)
+        assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max()) + 1e-12, n
+
+
+@pytest.mark.gpu
 def test_persistent_attention_scratch_under_changing_reset_patterns():
     """The dS-by-distance / P scratch lives across layers and steps and is never cleared; with reset_mems the kernel
     zero-writes the distances of the memory tiles a fresh sequence skips.  Ten steps with a different reset pattern each
