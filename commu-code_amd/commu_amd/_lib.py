@@ -76,7 +76,7 @@ PROTOTYPES = {
     "commu_embed_bwd": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_i, C.c_uint, c_f, c_p],
     "commu_embed_bwd_ws_rows": [c_i, c_i],
     "commu_embed_bwd_sorted": [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_f, c_i, C.c_uint, c_f, c_p],
-    "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, C.c_uint, c_f, c_p],
+    "commu_posemb_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_bwd_nblocks": [c_i],
     "commu_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, C.c_uint, c_f, c_p],
@@ -147,7 +147,7 @@ PROTOTYPES = {
     "commu_pack_batch": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_p, c_p],
     "commu_gemm_nt_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p],
     "commu_embed_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
-    "commu_posemb_f32": [c_p, c_p, c_i, c_i, c_i, c_p],
+    "commu_posemb_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "commu_layernorm_f32": [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "commu_relattn_f32": [c_p, c_i, c_p, c_p, C.c_longlong, C.c_longlong, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
                           c_i, c_i, c_i, c_i, c_i, c_f, c_p],

@@ -64,7 +64,7 @@ class DecodeState:
         self.kc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)      # head-major: contiguous per (b, h)
         self.vc = torch.zeros(L, B, H, Lmax, DH, device=dev, dtype=BF16)
         self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
-        self._pd = ops.posemb(model.pos_emb.inv_freq, Lmax, model.d_model, ld=D)
+        self._pd = ops.posemb(model.pos_emb.inv_freq, Lmax, model.d_model, ld=D, clamp_len=int(model.clamp_len))
         self.rd = [ops.gemm_nt(self._pd, model._weights(i)["r"]) for i in range(L)]
         self.logits = torch.zeros(B, VPAD, device=dev, dtype=F32)          # persistent: re-draws read them again (Q5)
         self.logits_new = torch.zeros(B, VPAD, device=dev, dtype=F32)      # this step's logits before the row select
@@ -97,7 +97,7 @@ class DecodeState:
         z = lambda *shape: torch.zeros(*shape, device=dev, dtype=F32)
         self.kc, self.vc = z(L, B, Lmax, HD), z(L, B, Lmax, HD)          # [layer][sequence][position][head * d_head]
         self.klen = torch.zeros(B, device=dev, dtype=torch.int32)
-        self._pd = ops.posemb_f32(m.pos_emb.inv_freq, Lmax, D)
+        self._pd = ops.posemb_f32(m.pos_emb.inv_freq, Lmax, D, clamp_len=int(m.clamp_len))
         self.rd = [z(Lmax, HD) for _ in range(L)]
         self.logits, self.logits_new = z(B, VPAD), z(B, VPAD)
         self.tail_ok = False

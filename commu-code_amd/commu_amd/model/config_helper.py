@@ -125,7 +125,7 @@ def get_default_cfg_inference():         # commu/model/config_helper.py:61-80
 
 
 def get_cfg(num_layers=6, num_heads=8, units=512, inner_size=1024, tgt_length=1024, mem_length=0,
-            batch_size=64, batch_chunk=1, dropout=0.1, attention_dropout=0.1, same_length=False, **train_kw):
+            batch_size=64, batch_chunk=1, dropout=0.1, attention_dropout=0.1, same_length=False, clamp_len=-1, **train_kw):
     """Reference config with overridden shape fields (the reference has no override mechanism:
     its defaults are hard-coded, config_helper.py:52-58)."""
     cfg = get_default_cfg_training()
@@ -134,6 +134,7 @@ def get_cfg(num_layers=6, num_heads=8, units=512, inner_size=1024, tgt_length=10
     cfg.MODEL.units, cfg.MODEL.inner_size = units, inner_size
     cfg.MODEL.dropout, cfg.MODEL.attention_dropout = dropout, attention_dropout
     cfg.MODEL.same_length = same_length
+    cfg.MODEL.clamp_len = clamp_len
     cfg.TRAIN.tgt_length, cfg.TRAIN.mem_length = tgt_length, mem_length
     cfg.TRAIN.batch_size, cfg.TRAIN.batch_chunk = batch_size, batch_chunk
     for k, v in train_kw.items():

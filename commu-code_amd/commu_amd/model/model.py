@@ -177,8 +177,6 @@ class MemTransformerLM(nn.Module):
         self.pos_emb = PositionalEmbedding(d_model)
         self.r_w_bias = nn.Parameter(torch.Tensor(n_head, d_head))      # model.py:491-492 (uninitialised)
         self.r_r_bias = nn.Parameter(torch.Tensor(n_head, d_head))
-        if self.clamp_len > 0:
-            raise CommuHipError("clamp_len > 0 is not used by the reference configs and is not built")
         if d_model % 4 or d_model > 1024 or d_head > 64 or d_head < 1 or self.n_token > VPAD:
             raise CommuHipError(f"unsupported shape: d_model={d_model} d_inner={d_inner} d_head={d_head} "
                                 "(this build needs d_model % 4 == 0, d_model <= 1024 and d_head <= 64)")
@@ -252,7 +250,7 @@ class MemTransformerLM(nn.Module):
         K = T + M
         E = self.word_emb.emb_layers[0].weight
         h = ops.embed_f32(data.contiguous().view(-1), E)                                   # model.py:585
-        pd = ops.posemb_f32(self.pos_emb.inv_freq, K, D)                                   # :578-584 (by distance)
+        pd = ops.posemb_f32(self.pos_emb.inv_freq, K, D, clamp_len=int(self.clamp_len))    # :578-584 (by distance)
         u, vb = self.r_w_bias.contiguous(), self.r_r_bias.contiguous()
         hids = [h]
         kv_out = []
@@ -547,7 +545,8 @@ class MemTransformerLM(nn.Module):
         # every layer's output goes straight into one [L+1, T*B, Dp] buffer: it IS the list of hidden states K9 needs
         hids = torch.empty(L + 1, TB, D, device=dev, dtype=BF16)
         h = ops.embed_fwd(tokens, self.word_emb.emb_layers[0].weight, out=hids[0], drop_p=p, drop_seed=ss(0))    # K1
-        pd = ops.posemb(self.pos_emb.inv_freq, K, Dt, drop_p=p, drop_seed=ss(1), ld=D)               # K2 (distance order)
+        pd = ops.posemb(self.pos_emb.inv_freq, K, Dt, drop_p=p, drop_seed=ss(1), ld=D,
+                        clamp_len=int(self.clamp_len))                                               # K2 (distance order)
         if need_grad:
             sv.T, sv.M, sv.B, sv.tokens, sv.reset, sv.pd = T, M, B, tokens, rst, pd
             sv.same_length, sv.mem_len = bool(self.same_length), int(self.mem_len)

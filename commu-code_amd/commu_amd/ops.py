@@ -415,10 +415,11 @@ def embed_bwd(tok, dX, dE, accumulate=True, drop_p=0.0, drop_seed=0, order=None)
     return dE
 
 
-def posemb(inv_freq, K, D, out=None, drop_p=0.0, drop_seed=0, ld=None):
+def posemb(inv_freq, K, D, out=None, drop_p=0.0, drop_seed=0, ld=None, clamp_len=-1):
+    """Sinusoid table by distance; clamp_len > 0: distances above it share its row (cfg.MODEL.clamp_len, model.py:581-582)."""
     if out is None:
         out = torch.empty(K, D if ld is None else ld, device=inv_freq.device, dtype=BF16)
-    call("commu_posemb_fwd", _p(inv_freq), _p(out), out.stride(0), K, D, int(drop_seed), float(drop_p), _s())
+    call("commu_posemb_fwd", _p(inv_freq), _p(out), out.stride(0), K, D, int(clamp_len), int(drop_seed), float(drop_p), _s())
     return out
 
 
@@ -950,12 +951,12 @@ def embed_f32(tok, E, out=None):
     return out
 
 
-def posemb_f32(inv_freq, n, D, out=None):
-    """model.py:142-147 by distance: row d = [sin(d * inv_freq) | cos(d * inv_freq)]."""
+def posemb_f32(inv_freq, n, D, out=None, clamp_len=-1):
+    """model.py:142-147 by distance: row d = [sin(p * inv_freq) | cos(p * inv_freq)], p = d or min(d, clamp_len)."""
     if out is None:
         out = torch.empty(n, D, device=inv_freq.device, dtype=F32)
     assert inv_freq.dtype == F32 and inv_freq.numel() == D // 2
-    call("commu_posemb_f32", _p(inv_freq), _p(out), _f32_2d(out, "out"), n, D, _s())
+    call("commu_posemb_f32", _p(inv_freq), _p(out), _f32_2d(out, "out"), n, D, int(clamp_len), _s())
     return out
 
 

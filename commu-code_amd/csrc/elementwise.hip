@@ -243,12 +243,13 @@ __global__ __launch_bounds__(256) void embed_bwd_fold_kernel(const int64_t* __re
 // K2: sinusoid table indexed by DISTANCE d (pos = d): out[d] = [sin(d f) | cos(d f)]
 // (commu/model/model.py:142-147; the reference's row k of pos_emb is distance klen-1-k).
 __global__ void posemb_kernel(const float* __restrict__ inv_freq, bf16* __restrict__ out, int ld,
-                              int K, int D, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
+                              int K, int D, int clamp_len, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
     const int half = D >> 1;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= K * half) return;
     const int d = idx / half, i = idx - d * half;
-    const float ang = (float)d * inv_freq[i];
+    // (model.py:581-582: positions above clamp_len share its row; the dropout mask below stays per table row)
+    const float ang = (float)(clamp_len > 0 ? min(d, clamp_len) : d) * inv_freq[i];
     float sv = sinf(ang), cv = cosf(ang);
     if (drop_thr) {
         sv = drop_keep(salted(drop_seed), (unsigned)d * (unsigned)D + (unsigned)i, drop_thr) ? sv * drop_scale : 0.f;
@@ -1027,12 +1028,12 @@ extern "C" int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, 
     return 0;
 }
 
-extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K, int D, unsigned drop_seed,
+extern "C" int commu_posemb_fwd(const float* inv_freq, void* out, int ld, int K, int D, int clamp_len, unsigned drop_seed,
                                 float drop_p, hipStream_t stream) {
     const int n = K * (D / 2);
     if (n <= 0) return 0;
     COMMU_LAUNCH(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, inv_freq, (bf16*)out,
-                       ld, K, D, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
+                       ld, K, D, clamp_len, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -129,19 +129,19 @@ extern "C" int commu_embed_f32(const long long* tok, const float* E, float* out,
 
 // model.py:142-147 by DISTANCE: out[d] = [sin(d * inv_freq) | cos(d * inv_freq)], d = 0 .. n - 1 (the reference's row m of a
 // K-row table is position K - 1 - m, and the rel-shift pairs query i / key j with position i + M - j: the distance)
-__global__ void posemb_f32_kernel(const float* __restrict__ inv_freq, float* __restrict__ out, int ld, int n, int D) {
+__global__ void posemb_f32_kernel(const float* __restrict__ inv_freq, float* __restrict__ out, int ld, int n, int D, int clamp_len) {
     const int d = blockIdx.x;
     const int half = D / 2;
     for (int c = threadIdx.x; c < half; c += blockDim.x) {
-        const float x = (float)d * inv_freq[c];          // (torch.ger: one fp32 product per entry)
+        const float x = (float)(clamp_len > 0 ? min(d, clamp_len) : d) * inv_freq[c];          // (torch.ger: one fp32 product per entry; :581-582)
         out[(size_t)d * ld + c] = sinf(x);
         out[(size_t)d * ld + half + c] = cosf(x);
     }
 }
 
-extern "C" int commu_posemb_f32(const float* inv_freq, float* out, int ld, int n, int D, hipStream_t stream) {
+extern "C" int commu_posemb_f32(const float* inv_freq, float* out, int ld, int n, int D, int clamp_len, hipStream_t stream) {
     if (n <= 0 || D % 2) return -22;
-    COMMU_LAUNCH(posemb_f32_kernel, dim3(n), dim3(128), 0, stream, inv_freq, out, ld, n, D);
+    COMMU_LAUNCH(posemb_f32_kernel, dim3(n), dim3(128), 0, stream, inv_freq, out, ld, n, D, clamp_len);
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -157,8 +157,9 @@ int commu_token_order(const int64_t* tok, int ntok, int V, int64_t* perm, int64_
 int commu_embed_bwd_sorted(const int64_t* perm, const int64_t* offs, const void* dX, int ldx, float* ws, int ntok, int D,
                            int V, float* dE, float scale, int accumulate, unsigned drop_seed, float drop_p,
                            hipStream_t stream);
-/* sinusoid table by distance d: out[d] = [sin(d f) | cos(d f)]  (PositionalEmbedding, model.py:136-152) */
-int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, unsigned drop_seed,
+/* sinusoid table by distance d: out[d] = [sin(p f) | cos(p f)], p = d, or min(d, clamp_len) when clamp_len > 0
+ * (PositionalEmbedding, model.py:136-152; cfg.MODEL.clamp_len, model.py:581-582) */
+int commu_posemb_fwd(const float* inv_freq, void* out_bf16, int ld, int K, int D, int clamp_len, unsigned drop_seed,
                      float drop_p, hipStream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm at model.py:171,214; applied :179,352) */
@@ -506,8 +507,9 @@ int commu_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C
 /* model.py:409-420: out[row][0:D] = E[tok[row]][0:D] * scale (scale = sqrt(d_model)) */
 int commu_embed_f32(const long long* tok, const float* E, float* out, int ld, int rows, int D, float scale,
                     hipStream_t stream);
-/* model.py:142-147 indexed by DISTANCE: out[d] = [sin(d * inv_freq) | cos(d * inv_freq)], d = 0 .. n-1 */
-int commu_posemb_f32(const float* inv_freq, float* out, int ld, int n, int D, hipStream_t stream);
+/* model.py:142-147 indexed by DISTANCE: out[d] = [sin(p * inv_freq) | cos(p * inv_freq)], d = 0 .. n-1, p = d or
+ * min(d, clamp_len) when clamp_len > 0 (model.py:581-582) */
+int commu_posemb_f32(const float* inv_freq, float* out, int ld, int n, int D, int clamp_len, hipStream_t stream);
 /* nn.LayerNorm (model.py:179,352), D <= 1024 */
 int commu_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows,
                         int D, float eps, hipStream_t stream);

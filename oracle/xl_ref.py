@@ -76,9 +76,12 @@ def init_params(s: XLShape, seed: int, std: float = 0.01,
     return p
 
 
-def sinusoid_table(klen: int, d_model: int, dtype=torch.float32) -> Tensor:
-    """P[k] = [sin(pos_k f) | cos(pos_k f)], pos_k = klen-1-k  (model.py:142-147,578-583)."""
+def sinusoid_table(klen: int, d_model: int, dtype=torch.float32, clamp_len: int = -1) -> Tensor:
+    """P[k] = [sin(pos_k f) | cos(pos_k f)], pos_k = klen-1-k, clamped to clamp_len when that is > 0
+    (model.py:142-147,578-583)."""
     pos = torch.arange(klen - 1, -1, -1.0, dtype=dtype)
+    if clamp_len > 0:
+        pos = pos.clamp(max=clamp_len)
     inv_freq = 1.0 / (10000 ** (torch.arange(0.0, d_model, 2.0, dtype=dtype) / d_model))
     ang = pos[:, None] * inv_freq[None, :]
     return torch.cat([ang.sin(), ang.cos()], dim=-1)
@@ -180,7 +183,7 @@ def decoder_layer(p: Dict[str, Tensor], li: int, s: XLShape, h: Tensor, mem: Opt
 
 
 def forward_hidden(p: Dict[str, Tensor], s: XLShape, tokens: Tensor, reset: Optional[Tensor],
-                   mems: Optional[Tensor], mem_len: int, same_length: bool, drop=_nodrop
+                   mems: Optional[Tensor], mem_len: int, same_length: bool, drop=_nodrop, clamp_len: int = -1
                    ) -> Tuple[Tensor, Optional[Tensor]]:
     """MemTransformerLM._forward in eval mode (model.py:540-604).
 
@@ -193,7 +196,7 @@ def forward_hidden(p: Dict[str, Tensor], s: XLShape, tokens: Tensor, reset: Opti
     M = 0 if mems is None or mems.numel() == 0 else mems.shape[1]
     K = T + M
     mask = attn_mask(T, M, B, reset, same_length, mem_len)
-    pos = drop(("pos", 0), sinusoid_table(K, D, h.dtype))               # model.py:586
+    pos = drop(("pos", 0), sinusoid_table(K, D, h.dtype, clamp_len))    # model.py:581-586
     hids = [h]
     for li in range(s.n_layer):
         mem = None if M == 0 else mems[li]
@@ -221,24 +224,24 @@ def logits_from_hidden(p: Dict[str, Tensor], hidden: Tensor) -> Tensor:
 
 
 def forward_loss(p, s: XLShape, data: Tensor, target: Tensor, reset, mems, mem_len: int,
-                 same_length: bool, drop=_nodrop) -> Tuple[Tensor, Optional[Tensor]]:
+                 same_length: bool, drop=_nodrop, clamp_len: int = -1) -> Tuple[Tensor, Optional[Tensor]]:
     """MemTransformerLM.forward (model.py:678-693): per-token NLL [T,B] and new mems.
     `drop(site, x)` (optional) applies a dropout mask at the reference's nn.Dropout sites."""
     if mems is None:
         mems = init_mems(s, mem_len, p["r_w_bias"].dtype)
-    hidden, new_mems = forward_hidden(p, s, data, reset, mems, mem_len, same_length, drop)
+    hidden, new_mems = forward_hidden(p, s, data, reset, mems, mem_len, same_length, drop, clamp_len)
     logits = logits_from_hidden(p, hidden)
     lse = torch.logsumexp(logits, dim=-1)
     nll = lse - torch.gather(logits, 2, target[..., None]).squeeze(-1)
     return nll, new_mems
 
 
-def forward_generate(p, s: XLShape, data: Tensor, mems, mem_len: int, same_length: bool = True
-                     ) -> Tuple[Tensor, Optional[Tensor]]:
+def forward_generate(p, s: XLShape, data: Tensor, mems, mem_len: int, same_length: bool = True,
+                     clamp_len: int = -1) -> Tuple[Tensor, Optional[Tensor]]:
     """MemTransformerLM.forward_generate (model.py:606-628): logits [T,B,V] and new mems."""
     if mems is None:
         mems = init_mems(s, mem_len, p["r_w_bias"].dtype)
-    hidden, new_mems = forward_hidden(p, s, data, None, mems, mem_len, same_length)
+    hidden, new_mems = forward_hidden(p, s, data, None, mems, mem_len, same_length, clamp_len=clamp_len)
     return logits_from_hidden(p, hidden), new_mems
 
 

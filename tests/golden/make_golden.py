@@ -73,9 +73,9 @@ def ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
-def make_cfg(L, H, D, DI, tgt, mem, same_length=False):
+def make_cfg(L, H, D, DI, tgt, mem, same_length=False, clamp_len=-1):
     return ns(MODEL=ns(num_layers=L, num_heads=H, units=D, inner_size=DI, dropout=0.0,
-                       attention_dropout=0.0, same_length=same_length, clamp_len=-1),
+                       attention_dropout=0.0, same_length=same_length, clamp_len=clamp_len),
               TRAIN=ns(tgt_length=tgt, mem_length=mem),
               INITIALIZER=ns(base_init=0.01, embed_init=0.01))
 
@@ -123,12 +123,13 @@ def save(name, **arrs):
 
 
 # ------------------------------------------------------------------------------------------------
-def g1(tag, L, H, D, DI, T, B, mem_len, same_length):
-    cfg = make_cfg(L, H, D, DI, T, mem_len, same_length)
+def g1(tag, L, H, D, DI, T, B, mem_len, same_length, clamp_len=-1):
+    cfg = make_cfg(L, H, D, DI, T, mem_len, same_length, clamp_len)
     model = build_model(cfg, 11, std=0.05)
     g = torch.Generator().manual_seed(5)
     out = sd_np(model)
     out["meta"] = np.array([L, H, D, DI, T, B, mem_len, int(same_length)])
+    out["clamp_len"] = np.array(clamp_len)          # cfg.MODEL.clamp_len (model.py:581-582: positions above it share one row)
     mems = None
     for seg in range(3):
         data = torch.randint(1, 729, (T, B), generator=g)
@@ -689,6 +690,8 @@ if __name__ == "__main__":
         g1("mem", 2, 2, 64, 128, 12, 3, 16, False)
         g1("nomem", 2, 2, 64, 128, 12, 3, 0, False)
         g1("dh50", 2, 2, 100, 136, 10, 2, 12, False)
+    if "g1" in which or "g1c" in which:
+        g1("clamp", 2, 2, 64, 128, 12, 3, 16, False, clamp_len=9)          # 28 key positions, the 18 farthest share position 9
     if "g2" in which:
         g2()
     if "g3" in which:

@@ -472,6 +472,19 @@ def test_posemb_distance_order():
     assert float((out.float().cpu() - ref).abs().max()) < 8e-3     # bf16 rounding of values in [-1,1]
 
 
+def test_posemb_clamp_len():
+    """cfg.MODEL.clamp_len (model.py:581-582): positions above it share its row of the table."""
+    o = ops()
+    K, D, C = 41, 64, 9
+    inv_freq = 1.0 / (10000 ** (torch.arange(0.0, D, 2.0) / D))
+    out = o.posemb(inv_freq.to(DEV), K, D, clamp_len=C).float().cpu()
+    ref = X.sinusoid_table(K, D, clamp_len=C).flip(0)
+    assert float((out - ref).abs().max()) < 8e-3
+    assert torch.equal(out[C:], out[C:C + 1].expand(K - C, D)) and not torch.equal(out[C - 1], out[C])
+    out32 = o.posemb_f32(inv_freq.to(DEV), K, D, clamp_len=C).cpu()
+    assert float((out32 - ref).abs().max()) < 4e-7
+
+
 @pytest.mark.parametrize("rows,D", [(5, 64), (300, 128), (1000, 512), (130, 1024)])
 def test_layernorm_fwd_bwd(rows, D):
     o = ops()

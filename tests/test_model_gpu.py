@@ -28,7 +28,8 @@ def build_from_fixture(z, same_length=None):
     from commu_amd.model.model import MemTransformerLM
     L, H, D, DI, T, B, mem_len, sl = [int(x) for x in z["meta"][:8]]
     cfg = get_cfg(num_layers=L, num_heads=H, units=D, inner_size=DI, tgt_length=T, mem_length=mem_len,
-                  dropout=0.0, attention_dropout=0.0, same_length=bool(sl) if same_length is None else same_length)
+                  dropout=0.0, attention_dropout=0.0, same_length=bool(sl) if same_length is None else same_length,
+                  clamp_len=int(z["clamp_len"]) if "clamp_len" in z.files else -1)
     model = MemTransformerLM(cfg, BaseVocab())
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p::")}
     sd["crit.out_layers.0.weight"] = sd["word_emb.emb_layers.0.weight"]
@@ -50,7 +51,8 @@ def relerr(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("tag", ["mem", "nomem", "dh50"])      # dh50: d_model 100, d_head 50 (zero-padded to 128 / 64)
+# dh50: d_model 100, d_head 50 (zero-padded to 128 / 64); clamp: cfg.MODEL.clamp_len = 9 (the reference's outputs with it)
+@pytest.mark.parametrize("tag", ["mem", "nomem", "dh50", "clamp"])
 def test_g1_forward_backward_vs_reference(golden_dir, tag):
     z = load(golden_dir, f"g1_train_{tag}.npz")
     model, cfg = build_from_fixture(z)

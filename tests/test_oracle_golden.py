@@ -28,17 +28,18 @@ def shape_of(meta):
     return X.XLShape(L, H, D, DI)
 
 
-@pytest.mark.parametrize("tag", ["mem", "nomem", "dh50"])
+@pytest.mark.parametrize("tag", ["mem", "nomem", "dh50", "clamp"])      # clamp: cfg.MODEL.clamp_len = 9 (model.py:581-582)
 def test_g1_forward_backward(golden_dir, tag):
     z = load(golden_dir, f"g1_train_{tag}.npz")
     s = shape_of(z["meta"])
     mem_len, same_length = int(z["meta"][6]), bool(z["meta"][7])
+    clamp_len = int(z["clamp_len"]) if "clamp_len" in z.files else -1
     p = {k: v.requires_grad_(True) for k, v in params_of(z).items()}
     mems = None
     for seg in range(3):
         data, target = torch.from_numpy(z[f"data{seg}"]), torch.from_numpy(z[f"target{seg}"])
         reset = torch.from_numpy(z[f"reset{seg}"])
-        nll, mems = X.forward_loss(p, s, data, target, reset, mems, mem_len, same_length)
+        nll, mems = X.forward_loss(p, s, data, target, reset, mems, mem_len, same_length, clamp_len=clamp_len)
         assert np.abs(nll.detach().numpy() - z[f"loss{seg}"]).max() < TOL
         if mem_len > 0:
             assert mems.shape == z[f"mems{seg}"].shape

@@ -118,6 +118,29 @@ def test_forward_generate_f32_vs_oracle(shape):
     assert worst < 1e-4
 
 
+def test_clamp_len_fixture_in_parity_mode(golden_dir):
+    """cfg.MODEL.clamp_len = 9 (model.py:581-582): the reference's OWN three segments (fixture g1_train_clamp) through
+    forward_generate in parity mode -- the memories it returns are the reference's to 1e-5 of their range (with the clamp
+    ignored they differ by ~1e-3: the bf16 tolerances could not tell), and the logits equal the oracle's with the clamp."""
+    from test_model_gpu import build_from_fixture
+    from test_oracle_golden import params_of, shape_of
+    z = load(golden_dir, "g1_train_clamp.npz")
+    model, _ = build_from_fixture(z)
+    assert model.clamp_len == 9
+    model.eval()
+    model.parity_fp32 = True
+    s, p = shape_of(z["meta"]), params_of(z)
+    mems, omems, omems_noclamp = None, None, None
+    for seg in range(2):          # (segment 2 resets a column: forward_generate has no reset_mems)
+        data = torch.from_numpy(z[f"data{seg}"])
+        with torch.no_grad():
+            ref, omems = X.forward_generate(p, s, data, omems, 16, False, clamp_len=9)
+            other, omems_noclamp = X.forward_generate(p, s, data, omems_noclamp, 16, False)
+        logits, mems = model.forward_generate(data.to(DEV), mems)
+        assert rel(logits, ref) < 1e-5 and rel(mems, z[f"mems{seg}"]) < 1e-5
+        assert rel(other, ref) > 1e-4          # the fixture does exercise the clamp
+
+
 def test_g2_forward_generate_fixture_in_parity_mode(golden_dir):
     """The reference's OWN outputs (fixture G2: context, four single-token steps, same_length with a short memory), which the
     bf16 path meets to 2e-2 of range, met to 1e-5 in parity mode."""
