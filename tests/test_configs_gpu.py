@@ -184,8 +184,10 @@ def test_bench_shape_full_batch_trains():
     assert losses[-1] < losses[1], losses                         # lr(0) = 0 (quirk Q7): step 0 does not move
 
 
-def test_cfg5_full_12_layers_with_memory_trains():
-    """configs[4] in full (12 layers, d_model 1024, 16 heads, FFN 2048, tgt_len 2048, mem_len 2048; bf16 operands):
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8_forward"])
+def test_cfg5_full_12_layers_with_memory_trains(fp8):
+    """configs[4] in full (12 layers, d_model 1024, 16 heads, FFN 2048, tgt_len 2048, mem_len 2048; bf16 operands, and --
+    as BASELINE.json names the config -- with the layers' forward Linear products in MX-fp8, `model.fp8_forward`):
     the oracle is too slow at this size, so the size-independent properties: the loss at random init is ~log V,
     every step is finite, the memory is carried ([13, 2048, B, 1024], equal to the layer outputs of the step that
     wrote it) and the loss goes down over optimiser steps on a repeated batch."""
@@ -197,6 +199,7 @@ def test_cfg5_full_12_layers_with_memory_trains():
                   batch_size=B, batch_chunk=1, dropout=0.1, attention_dropout=0.1)
     model = build_model(cfg, BaseVocab(), torch.device(DEV), seed=3)
     model.train()
+    model.fp8_forward = fp8
     tr = Trainer(model, cfg, num_gpus=1)
     d, t, r, n = synthetic_batch(2048, B, torch.device(DEV), seed=9)
     r = torch.zeros_like(r)                                       # keep the memory: attention spans 4096 positions
