@@ -97,9 +97,72 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         }
 }
 
+// Decode-step form (M <= 64 rows: one token per sequence): a workgroup owns 16 output columns and all rows, its four waves
+// split K four ways and every lane feeds FOUR MFMAs from one 16-byte load per operand -- lane group g of k-block t holds
+// k = 16 t + 4 g + s for MFMA s, the same bijection on both operands --, partial tiles are added through LDS.  N / 16
+// workgroups stream the weight matrix once (the 64 x 64 tile above would put 24 workgroups on a [1536, 512] weight).
+__global__ __launch_bounds__(256) void gemm_nt_f32_skinny_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                                 int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                                 const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                 int ldr, int relu) {
+    __shared__ f32x4 part[4][4][64];          // [wave][row tile][lane]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int ncol = min(n0 + r16, N - 1);
+    const float* bp = B + (size_t)ncol * ldb;
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kq = (K + 63) / 64 * 16;          // k per wave, a multiple of 16
+    const int kbeg = w * kq, kend = min(K, kbeg + kq);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const int kk = k0 + 4 * g;
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        const f4 bv = (kk + 3 < kend) ? *(const f4*)(bp + kk) : z;          // (K % 4 == 0, 16-byte aligned rows: the launcher checks)
+        f4 av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = 16 * mt + r16;
+            av[mt] = (row < M && kk + 3 < kend) ? *(const f4*)(A + (size_t)row * lda + kk) : z;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv.y, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv.z, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv.w, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) part[w][mt][lane] = acc[mt];
+    __syncthreads();
+    // wave w finishes row tile w: D lane l, register r = C[16 w + 4 (l >> 4) + r][n0 + (l & 15)]
+    f32x4 sum = part[0][w][lane];
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) sum += part[ww][w][lane];
+    const int col = n0 + r16;
+    if (col >= N) return;
+    const float bs = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + 4 * g + r;
+        if (row >= M) continue;
+        float v = sum[r] + bs;
+        if (relu) v = fmaxf(v, 0.f);
+        if (resid) v += resid[(size_t)row * ldr + col];
+        C[(size_t)row * ldc + col] = v;
+    }
+}
+
 extern "C" int commu_gemm_nt_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                                  const float* bias, const float* resid, int ldr, int relu, hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return -22;
+    if (M <= 64 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) % 16 == 0)) {
+        COMMU_LAUNCH(gemm_nt_f32_skinny_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, bias,
+                     resid, ldr, relu);
+        COMMU_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid((N + PG_BN - 1) / PG_BN, (M + PG_BM - 1) / PG_BM);
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
     if (vec)
