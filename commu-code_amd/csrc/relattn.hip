@@ -1340,11 +1340,14 @@ __global__ __launch_bounds__(64 * NW) void relattn_bwd_kv_kernel(const AttnArgs 
 // measured too: the 128-register forward kernel pays more for the extra stores than both backward kernels gain.)
 // key-stationary: dk, dv (as relattn_bwd_kv_kernel: wave w owns key columns 16w..16w+15 of the 64-column tile).
 template <bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void relattn_bwd_kv2_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void relattn_bwd_kv2_kernel(const AttnArgs a) {
     constexpr int DH = 64, NW = 4, KS = 2, DB = 4, KCOLS = 64, NTHR = 256;
-    __shared__ __attribute__((aligned(16))) bf16 sQu[64 * DH];
-    __shared__ __attribute__((aligned(16))) bf16 sdO[64 * DH];
-    __shared__ __attribute__((aligned(16))) float sRs[64], sDl[64];
+    // (q+u) and dO tiles arrive by LDS-DMA into double buffers, the per-row scale / delta into double vectors: ONE barrier
+    // per 64-query step, no staging registers, no tile writes from registers (the register-staged form needed two barriers
+    // and 16 registers per lane in a kernel that lives at the 168-register / three-waves-per-SIMD edge)
+    __shared__ __attribute__((aligned(1024))) bf16 sQu2[2][64 * DH];
+    __shared__ __attribute__((aligned(1024))) bf16 sdO2[2][64 * DH];
+    __shared__ __attribute__((aligned(16))) float sRs2[2][64], sDl2[2][64];
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, g = lane >> 4;
     const int T = a.T, M = a.M, B = a.B, K = T + M, HD = a.H * DH;
@@ -1364,9 +1367,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const unsigned qsb = (unsigned)B * HD * 2u, osb = (unsigned)B * a.ld_o * 2u;
     const srd_t srdQu = make_srd(a.qu2 + (size_t)b * HD + h * DH, ((size_t)(T - 1) * B * HD + DH) * 2);
     const srd_t srdO = make_srd(a.dout + (size_t)b * a.ld_o + h * DH, ((size_t)(T - 1) * B * a.ld_o + DH) * 2);
-    Stager<64, DH, NTHR> stQu, stO;
-    stQu.init(qsb, tid);
-    stO.init(osb, tid);
+    // DMA piece j of wave w fills tile rows 16 w + 8 j + (lane >> 3); LDS slot (lane & 7) of a row holds logical 16-byte
+    // chunk (lane & 7) ^ (row & 7) (the image frag / frag_tr_rm read: swz<64>)
+    unsigned voffQ[2], voffO[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = 16 * w + 8 * j + (lane >> 3), c = (lane & 7) ^ (R & 7);
+        voffQ[j] = (unsigned)R * qsb + (unsigned)c * 16u;
+        voffO[j] = (unsigned)R * osb + (unsigned)c * 16u;
+    }
+    const unsigned ldsQ = (unsigned)(size_t)(LDS_AS bf16*)&sQu2[0][0] + (unsigned)(w * 2048);
+    const unsigned ldsO = (unsigned)(size_t)(LDS_AS bf16*)&sdO2[0][0] + (unsigned)(w * 2048);
     const size_t bh = (size_t)b * a.H + h;
 
     for (int rep = 0; rep < 2; ++rep) {
@@ -1394,10 +1405,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bf16* pcol = a.pbuf + bh * IB * JT * 1024 + (size_t)jt * 1024 + pt_off(16 * w + r16, g);
     float prs = 0.f, pdl = 0.f;
     bf16x4 pun[4];
-    auto issue = [&](int it) {
+    auto issue = [&](int it, int buf) {
         const int i0 = it * 64;
-        stQu.load(srdQu, (unsigned)i0 * qsb);
-        stO.load(srdO, (unsigned)i0 * osb);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            lds_dma16s(srdQu, voffQ[j], (unsigned)i0 * qsb, ldsQ + (unsigned)(buf * 64 * DH * 2 + j * 1024));
+            lds_dma16s(srdO, voffO[j], (unsigned)i0 * osb, ldsO + (unsigned)(buf * 64 * DH * 2 + j * 1024));
+        }
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)          // rows beyond the last 16-row block: clamp (their row scale is 0)
             pun[rb] = *(const bf16x4*)(pcol + (size_t)min((i0 >> 4) + rb, IB - 1) * JT * 1024);
@@ -1407,22 +1421,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             pdl = a.delta[bh * T + min(i, T - 1)] / dsc;
         }
     };
-    auto commit = [&]() {
-        stQu.store(sQu);
-        stO.store(sdO);
-        if (tid < 64) { sRs[tid] = prs; sDl[tid] = pdl; }
+    auto commit = [&](int buf) {          // the per-row vectors of the step just requested (wave 0's lanes)
+        if (tid < 64) { sRs2[buf][tid] = prs; sDl2[buf][tid] = pdl; }
     };
     if (it_lo <= it_hi) {
-        issue(it_lo);
-        commit();
+        issue(it_lo, 0);
+        commit(0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int it = it_lo; it <= it_hi; ++it) {
-        const int i0 = it * 64;
+        const int i0 = it * 64, cur = (it - it_lo) & 1;
+        const bf16* sQu = sQu2[cur];
+        const bf16* sdO = sdO2[cur];
+        const float* sRs = sRs2[cur];
+        const float* sDl = sDl2[cur];
         bf16x4 pu[4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) pu[rb] = pun[rb];
-        if (it < it_hi) issue(it + 1);
+        // (the other buffers were last read in the previous step, which every wave has left: the barrier below)
+        if (it < it_hi) issue(it + 1, cur ^ 1);
 
         bf16x4 pb[4], dsb[4];     // per row block: P and dS'' for rows 16rb + 4g + reg, col r16
 #pragma unroll
@@ -1472,8 +1490,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
         }
-        __syncthreads();
-        if (it < it_hi) commit();
+        if (it < it_hi) commit(cur ^ 1);
+        // the next step's tiles have landed (and its P values: they have had this step's arithmetic to arrive)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #pragma unroll

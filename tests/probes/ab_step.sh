@@ -1,9 +1,12 @@
 #!/bin/bash
-# interleaved step-time A/B of two trees on one box: ab_step.sh <treeA> <treeB> [reps]   (trees relative to the repo root, "." = this tree)
+# the bench step, lib/libcommu_hip_prev.so against the current library, three interleaved pairs
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-A=$1; B=$2; reps=${3:-3}
-for r in $(seq $reps); do
-  for t in $A $B; do
-    echo -n "$t: "; (cd $t && python bench.py --no-extra --no-decode --no-cpu-baseline --no-graph ${AB_ARGS} | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")
-  done
-done
+L=commu-code_amd/lib
+cp $L/libcommu_hip.so $L/libcommu_hip_new.so
+for i in 1 2 3; do for v in prev new; do
+  cp $L/libcommu_hip_$v.so $L/libcommu_hip.so
+  python3 bench.py --no-extra --no-decode --no-cpu-baseline ${AB_ARGS} 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['ms_per_step'], {k: round(v,4) for k,v in d['roofline']['time_share'].items() if 'attn' in k})"
+done; done
+cp $L/libcommu_hip_new.so $L/libcommu_hip.so
