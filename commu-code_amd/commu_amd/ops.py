@@ -748,12 +748,12 @@ POISON_SCRATCH = False      # tests: fill uninitialised scratch with NaN to prov
 # normalisation arithmetic cost a latency-bound skinny GEMM more than the launch they save -- so it is OFF by default.
 FUSE_DECODE_LN = False
 STORE_ATTN_P = True         # backward: bwd_q stores P for bwd_kv (d_head 64); False: both kernels recompute it
-# delta = rowsum(o . dO): inside the query-stationary kernel (commu_attn_bwd_desc.o; False, the default since round 5) or the
-# separate commu_attn_delta launch (True).  In the step the two take the same time (round 4: 16.35 / 16.44 vs 16.36 / 16.44 ms;
-# round 5, three interleaved pairs: 15.92-15.95 both): the 28 us launch goes, every one of bwd_q's 8192 short-lived workgroups
-# pays a longer prologue -- but the in-kernel form reads `o` once (67 MB) where the launch read o and dO (134 MB) and wrote and
-# re-read delta: one launch and 0.4 GB of HBM traffic per step less at equal time, on a step that is traffic-bound.
-DELTA_KERNEL = _os.environ.get("COMMU_DELTA_KERNEL", "0") == "1"          # (COMMU_DELTA_KERNEL=1: the separate launch)
+# delta = rowsum(o . dO): the separate commu_attn_delta launch (True, the default) or inside the query-stationary kernel
+# (commu_attn_bwd_desc.o).  In the step the two take the same time (round 4: 16.35 / 16.44 vs 16.36 / 16.44 ms; round 5, three
+# interleaved pairs: 15.92-15.95 ms both): in-kernel, the 28 us launch and 0.35 GB of HBM traffic per step go (o is read once
+# where the launch reads o and dO), but every one of bwd_q's 8192 short-lived workgroups pays a longer prologue (0.588 against
+# 0.558 ms per launch in the step).  Equal: the kernel stays lean and the launch stays (COMMU_DELTA_KERNEL=0 selects the other).
+DELTA_KERNEL = _os.environ.get("COMMU_DELTA_KERNEL", "1") != "0"
 NO_FUSED_BAND = False       # tests / A-B runs: keep the two band GEMMs instead of commu_relattn_bwd_band
 
 
