@@ -245,3 +245,50 @@ def test_g6_greedy_reference_traces_in_parity_mode(golden_dir, tags):
         ref_trace = [tuple(t) for t in z[f"{tag}_trace"].tolist()]
         assert seqs[b][:len(ref)] == ref, tag
         assert gen.trace[b][:len(ref_trace)] == ref_trace, tag
+
+
+def test_generate_cli_parity_flag(golden_dir, tmp_path):
+    """`generate.py --parity` end to end on the reference-written checkpoint: the model initialiser switches the model to the
+    fp32 mode, the decode state it builds is the fp32 one, sequences.json is written.  Greedy (--temperature 0) so that the run
+    is deterministic: two invocations give the same sequences."""
+    import json
+    import test_model_gpu as TM
+    z = load(golden_dir, "g10_checkpoint.npz")
+    cli = TM._load_script("generate")
+    parsers = cli.parse_args()
+    prog = "-".join(["Am"] * 8 + ["G"] * 8 + ["F"] * 8 + ["E"] * 8)
+    argv = ["--checkpoint_dir", os.path.join(golden_dir, "g10_checkpoint.pt"), "--parity", "--output_dir", str(tmp_path / "out"),
+            "--bpm", "70", "--audio_key", "aminor", "--time_signature", "4/4", "--pitch_range", "mid_high",
+            "--num_measures", "8", "--inst", "acoustic_piano", "--genre", "newage", "--min_velocity", "60",
+            "--max_velocity", "80", "--track_role", "main_melody", "--rhythm", "standard", "--chord_progression",
+            prog + "-" + prog, "--num_generate", "1", "--max_rounds", "1", "--temperature", "0", "--gpus", "1"]
+    margs, _ = parsers["model_args"].parse_known_args(argv)
+    iargs, _ = parsers["input_args"].parse_known_args(argv)
+    assert margs.parity is True
+    import commu_amd.midi_generator.model_initializer as mi
+    from commu_amd import generate as G
+    orig = mi.get_default_cfg_inference
+    built = []
+    orig_init = G.DecodeState.__init__
+
+    def spy(self, model, B, Lmax):
+        orig_init(self, model, B, Lmax)
+        built.append(self.parity)
+
+    def short_cfg():
+        c = orig()
+        c.defrost()
+        c.GENERATION.generation_length = 64
+        return c
+    mi.get_default_cfg_inference = short_cfg
+    G.DecodeState.__init__ = spy
+    try:
+        outs = []
+        for _ in range(2):
+            cli.main(margs, iargs, training_cfg=TM._g10_cfg(z, False))
+            outs.append(json.load(open(tmp_path / "out" / "sequences.json")))
+    finally:
+        mi.get_default_cfg_inference = orig
+        G.DecodeState.__init__ = orig_init
+    assert built and all(built)
+    assert outs[0] == outs[1] and outs[0]["encoded_meta"][0] == 574
