@@ -479,10 +479,15 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
                 "why_hbm": "the forward pass saves its probabilities: this kernel recomputes no scores (2 of the former 4 "
                            "products) and streams ~2 GB per launch",
                 "time_share": share, "event_sampling": "every 4th step of the timed region"}
-    return {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom, args),
-            "flops_per_launch": fl_launch, "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
-            "time_share": share, "event_sampling": "every 4th step of the timed region"}
+    traffic = pmc_traffic(dom, args)
+    out = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+           "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+           "flops_per_launch": fl_launch, "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
+           "time_share": share, "event_sampling": "every 4th step of the timed region"}
+    if traffic:          # the same launch against the OTHER roof: measured HBM bytes / this run's launch time
+        gbs = traffic / (avg_ms * 1e-3) / 1e9
+        out["hbm_view"] = {"measured_traffic_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return out
 
 
 def iterator_bench(args, dev, steps, warmup, resident_ms):
