@@ -95,33 +95,40 @@ __device__ __forceinline__ void g8_store(const G8Args& a, f32x4 (&acc)[4][8], in
                           (!(flags & COMMU_EPI_RESID) || (a.ldr % 8) == 0) &&
                           (!(flags & COMMU_EPI_RELUMASK) || (a.ldm % 8) == 0);
     if (interior) {
+        // Order: the two 64-byte halves of a row's 128-byte line leave in CONSECUTIVE store instructions (a line whose halves
+        // arrive far apart is written back twice: 1.4x the output bytes at the memory interface, tests/probes/write_amp.sh).
+        float bv[2][8];
+        if (flags & COMMU_EPI_BIAS) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = nbase + 32 * j + 8 * g;
-            float bv[8];
-            if (flags & COMMU_EPI_BIAS) {
+            for (int j = 0; j < 2; ++j) {
+                const int n = nbase + 32 * j + 8 * g;
                 const f32x4 b0 = *(const f32x4*)(a.bias + n), b1 = *(const f32x4*)(a.bias + n + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                for (int e = 0; e < 4; ++e) { bv[j][e] = b0[e]; bv[j][4 + e] = b1[e]; }
             }
-            // all of this column half's residual (or ReLU-mask: never both, see gemm8_nt_eligible) vectors are
-            // requested before the first is used
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // all of this row half's residual (or ReLU-mask: never both, see gemm8_nt_eligible) vectors are requested
+            // before the first is used
             bf16x8 aux[8];
             if (flags & (COMMU_EPI_RESID | COMMU_EPI_RELUMASK)) {
                 const bf16* ap = (flags & COMMU_EPI_RESID) ? a.resid : a.rmask;
                 const int lda_ = (flags & COMMU_EPI_RESID) ? a.ldr : a.ldm;
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) aux[mi] = ld_bf16x8(ap + (size_t)(mbase + 16 * mi + r16) * lda_ + n);
+                for (int q = 0; q < 8; ++q)
+                    aux[q] = ld_bf16x8(ap + (size_t)(mbase + 16 * (4 * h + (q >> 1)) + r16) * lda_ + nbase + 32 * (q & 1) + 8 * g);
             }
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = mbase + 16 * mi + r16;
+            for (int q = 0; q < 8; ++q) {
+                const int mi = 4 * h + (q >> 1), j = q & 1;
+                const int m = mbase + 16 * mi + r16, n = nbase + 32 * j + 8 * g;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[2 * j + (e >> 2)][mi][e & 3];
                 if (flags & COMMU_EPI_BIAS) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                    for (int e = 0; e < 8; ++e) v[e] += bv[j][e];
                 }
                 if (flags & COMMU_EPI_RELU) {
 #pragma unroll
@@ -139,11 +146,11 @@ __device__ __forceinline__ void g8_store(const G8Args& a, f32x4 (&acc)[4][8], in
                 }
                 if (flags & COMMU_EPI_RESID) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bf2f(aux[mi][e]);
+                    for (int e = 0; e < 8; ++e) v[e] += bf2f(aux[q][e]);
                 }
                 if (flags & COMMU_EPI_RELUMASK) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf2f(aux[mi][e]) > 0.f) ? v[e] * a.mask_scale : 0.f;
+                    for (int e = 0; e < 8; ++e) v[e] = (bf2f(aux[q][e]) > 0.f) ? v[e] * a.mask_scale : 0.f;
                 }
                 if (OUT_F32) {
                     float* C = (float*)a.C + (size_t)m * a.ldc + n;
@@ -180,23 +187,22 @@ __device__ __forceinline__ void g8_store(const G8Args& a, f32x4 (&acc)[4][8], in
     }
 }
 
-// Pipelined epilogue: ONE quadrant of an interior wave's outputs -- column half J (32 columns), row half XH (64 rows) --
-// through bias -> relu -> dropout, stored as four 16-byte pieces per lane; the quadrant's accumulators are cleared for the
-// output tile that is already being accumulated.  Called from the main loop, one quadrant per phase of the NEXT tile's
-// first K-tile (phase p's MFMAs are the first to touch quadrant p again), so the conversion, the hash and the store
-// issue of one wave row run under the other row's MFMAs instead of in a burst with the matrix pipe idle.
+// Pipelined epilogue: an interior wave's outputs leave through bias -> relu -> dropout as 16-byte pieces per lane, one ROW HALF
+// (64 rows x both 32-column halves: two quadrants) in phase 1 and the other in phase 3 of the NEXT tile's first K-tile --
+// phase p's MFMAs are the first to touch quadrant p again, so quadrants 0 and 1 are still intact in phase 1 and 2, 3 in phase 3 --
+// with the accumulators cleared for the tile that is already being accumulated: the conversion, the hash and the store issue
+// of one wave row run under the other row's MFMAs instead of in a burst with the matrix pipe idle.
 __device__ __forceinline__ bool g8_interior(const G8Args& a, int mbase, int nbase) {
     return (mbase + 128 <= a.M) && (nbase + 64 <= a.N) && (a.ldc % 8) == 0;
 }
 
-template <bool OUT_F32, int J, int XH, int BITS = 0>
-__device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc)[4][8], const float (&bv)[8], int mbase,
-                                         int nbase, int r16, int g, unsigned* bits_out = nullptr, unsigned bits_in = 0u) {
+// (one 16-row block m4 of the quadrant)
+template <bool OUT_F32, int J, int XH, int BITS>
+__device__ __forceinline__ void g8_drain_piece(const G8Args& a, int flags, f32x4 (&acc)[4][8], const float (&bv)[8], int mbase,
+                                               int nbase, int r16, int g, int m4, unsigned& word, unsigned bits_in) {
     const int N = a.N;
     const int n = nbase + 32 * J + 8 * g;
-    unsigned word = 0u;          // BITS 1: (C > 0) of this lane's 32 outputs of the quadrant, bit 8 m4 + e
-#pragma unroll
-    for (int m4 = 0; m4 < 4; ++m4) {
+    {
         const int mi = 4 * XH + m4;
         const int m = mbase + 16 * mi + r16;
         float v[8];
@@ -247,10 +253,27 @@ __device__ __forceinline__ void g8_drain(const G8Args& a, int flags, f32x4 (&acc
         acc[2 * J][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[2 * J + 1][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (BITS == 1) *bits_out = word;
 }
 
-// PIPE: the finished tile of an interior wave is written during the next tile's first K-tile (g8_drain; epilogues without an
+// Both column halves of row half XH, row block by row block: the two 64-byte halves of an output row's 128-byte line leave in
+// consecutive store instructions (halves that arrive a phase apart are written back twice for 11-20 % of the lines,
+// tests/probes/write_amp.sh).  Quadrant numbers (phase order of the MFMAs): (J0,XH0) 0, (J1,XH0) 1, (J1,XH1) 2, (J0,XH1) 3.
+template <bool OUT_F32, int XH, int BITS = 0>
+__device__ __forceinline__ void g8_drain_rows(const G8Args& a, int flags, f32x4 (&acc)[4][8], const float (&bv)[2][8], int mbase,
+                                              int nbase, int r16, int g, unsigned* bits_out, unsigned bits_in0, unsigned bits_in1) {
+    unsigned word0 = 0u, word1 = 0u;
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+        g8_drain_piece<OUT_F32, 0, XH, BITS>(a, flags, acc, bv[0], mbase, nbase, r16, g, m4, word0, bits_in0);
+        g8_drain_piece<OUT_F32, 1, XH, BITS>(a, flags, acc, bv[1], mbase, nbase, r16, g, m4, word1, bits_in1);
+    }
+    if (BITS == 1) {
+        bits_out[64 * (XH ? 3 : 0)] = word0;
+        bits_out[64 * (XH ? 2 : 1)] = word1;
+    }
+}
+
+// PIPE: the finished tile of an interior wave is written during the next tile's first K-tile (g8_drain_rows; epilogues without an
 // auxiliary operand) instead of in one burst
 // (PIPE 2: + one bit per output, (C > 0), to the word buffer a.rmask; PIPE 3: ReLU backward from such a buffer -- the
 //  launcher guarantees that every wave is interior.  Word of (tile, wave, quadrant q in phase order, lane):
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             if (v1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (PIPE && pend) g8_drain<OUT_F32, 0, 0, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits + 0, PIPE == 3 ? rbl[0] : 0u);
+        if (PIPE && pend) g8_drain_rows<OUT_F32, 0, BITS>(a, pflags, acc, bvl, pmb, pnb, r16, g, pbits, PIPE == 3 ? rbl[0] : 0u, PIPE == 3 ? rbl[64] : 0u);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -440,7 +463,6 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             wf[ni][1] = G8_FRAG(pbo + Q_WHI * HT_BYTES + wo1 + ni * 2048);
         }
         if (v2) stage(Q_XLO, c2, pb);
-        if (PIPE && pend) g8_drain<OUT_F32, 1, 0, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 64, PIPE == 3 ? rbl[64] : 0u);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
             xf[mi][1] = G8_FRAG(pbo + Q_XHI * HT_BYTES + xo1 + mi * 2048);
         }
         if (v2) stage(Q_WHI, c2, pb);
-        if (PIPE && pend) g8_drain<OUT_F32, 1, 1, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 128, PIPE == 3 ? rbl[128] : 0u);
+        if (PIPE && pend) g8_drain_rows<OUT_F32, 1, BITS>(a, pflags, acc, bvl, pmb, pnb, r16, g, pbits, PIPE == 3 ? rbl[192] : 0u, PIPE == 3 ? rbl[128] : 0u);
         G8_WAIT_LGKM();
         G8_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -480,7 +502,6 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
         }
         if (v2) stage(Q_XHI, c2, pb);
         if (PIPE && pend) {
-            g8_drain<OUT_F32, 0, 1, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits + 192, PIPE == 3 ? rbl[192] : 0u);
             // (vmcnt retires in order: the K-tile needed next was complete with phase 1's Wlo pieces; younger than those are the
             //  three half-tiles of phases 2-4 and the 4 x 4 (fp32 output: 4 x 8; with sign words: 4 x 5) output stores of the
             //  four drains)
@@ -538,10 +559,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(const G8Args a) {
     }
     if (PIPE && pend) {          // the last tile of this workgroup
         if (PIPE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        g8_drain<OUT_F32, 0, 0, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits, PIPE == 3 ? rbl[0] : 0u);
-        g8_drain<OUT_F32, 1, 0, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 64, PIPE == 3 ? rbl[64] : 0u);
-        g8_drain<OUT_F32, 1, 1, BITS>(a, pflags, acc, bvl[1], pmb, pnb, r16, g, pbits + 128, PIPE == 3 ? rbl[128] : 0u);
-        g8_drain<OUT_F32, 0, 1, BITS>(a, pflags, acc, bvl[0], pmb, pnb, r16, g, pbits + 192, PIPE == 3 ? rbl[192] : 0u);
+        g8_drain_rows<OUT_F32, 0, BITS>(a, pflags, acc, bvl, pmb, pnb, r16, g, pbits, PIPE == 3 ? rbl[0] : 0u, PIPE == 3 ? rbl[64] : 0u);
+        g8_drain_rows<OUT_F32, 1, BITS>(a, pflags, acc, bvl, pmb, pnb, r16, g, pbits, PIPE == 3 ? rbl[192] : 0u, PIPE == 3 ? rbl[128] : 0u);
     }
     if (wr == 0) G8_BAR();          // pairs with the stagger barrier of the second wave row
 #undef G8_FRAG
