@@ -666,9 +666,12 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // column sums of dY (a bias gradient) ride along in the workgroups of the first K-tile column: wave (wr, wc) multiplies
-    // its dY fragments of column block wc by a fragment of ones -- 2 MFMAs beside the 32 of phases 1 and 3
-    const bool csum = colsum_off >= 0 && k0 == 0;
+    // column sums of dY (a bias gradient) ride along: wave (wr, wc) multiplies its dY fragments of column block wc by a fragment
+    // of ones -- 2 MFMAs beside the 32 of phases 1 and 3.  EVERY K-tile column of the problem does them and the first one writes:
+    // the workgroups that share a dY column block must keep the same pace -- with the extra MFMAs on half of them the others ran
+    // ahead, out of the L2's reach, and the laggards fetched their operands again (+13 % / +19 % of the launch's bytes with one /
+    // two such problems in the group, tests/probes/tn8_reads.py)
+    const bool csum = colsum_off >= 0;          // (every K-tile column does the work -- equal pace, see below -- the first one writes)
     f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     typedef __attribute__((ext_vector_type(4))) unsigned tn_u32x4;
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (tn_u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const Tn8Args a) {
             if (k < Kc) *(f32x4*)(out + (size_t)n * Kc + k) = acc[wb][xb];
         }
     }
-    if (csum && g == 0) {          // every row of the ones product is the column sum: row 0 (lanes g == 0, register 0)
+    if (csum && k0 == 0 && g == 0) {          // every row of the ones product is the column sum: row 0 (lanes g == 0, register 0)
         float* cs = a.slabs + (size_t)slice * a.slab_stride + colsum_off;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
