@@ -13,11 +13,11 @@ ops.attn_bwd_kv_generation(int(os.environ.get("COMMU_ATTN_KV_GEN", "0")))     # 
 B = int(os.environ.get("AB_B", 16))
 T = int(os.environ.get("AB_T", 1024))
 M = int(os.environ.get("AB_M", 0))
-H, DH = 8, 64
+H, DH = int(os.environ.get("AB_H", 8)), 64
 REPS = int(os.environ.get("AB_REPS", 3))
 WHAT = os.environ.get("AB_WHAT", "fwd,bwd")
 DROP = float(os.environ.get("AB_DROP", 0.0))
-ops.FWD_SAVES_P = os.environ.get("AB_SAVEP", "1") != "0"          # forward-saved probabilities (the training path)
+ops.FWD_SAVES_P = os.environ.get("AB_SAVEP", "0") != "0"          # forward-saved probabilities (opt-in; the training default is off)
 dev = "cuda"
 K = T + M
 HD = H * DH
