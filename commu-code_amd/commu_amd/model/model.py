@@ -129,6 +129,9 @@ class _XLLoss(torch.autograd.Function):
     def forward(ctx, model, data, target, reset, mems, *params):
         loss, new_mems, saved = model._run_forward(data, target, reset, mems, need_grad=True)
         ctx.model, ctx.saved = model, saved
+        # (without this autograd hands backward() a ZERO tensor of new_mems' shape -- [L+1, M, B, D]: a 0.47-GB fill per step
+        #  at the bench shape with mem_len 1024 -- for an output that is marked non-differentiable)
+        ctx.set_materialize_grads(False)
         if new_mems is None:
             new_mems = torch.empty(0, device=data.device)
         ctx.mark_non_differentiable(new_mems)
@@ -140,6 +143,8 @@ class _XLLoss(torch.autograd.Function):
         ctx.saved = None
         if saved is None:
             raise CommuHipError("backward called twice on the same forward")
+        if dloss is None:          # (only new_mems was used downstream: nothing to differentiate)
+            return (None,) * (5 + len(model._flat["params"]))
         grads = model._run_backward(saved, dloss.contiguous())
         return (None, None, None, None, None) + grads
 

@@ -582,6 +582,9 @@ def test_adam_and_grad_norm_match_oracle():
         o.adam_step(pd, gd, m, v, pb, 1e-2, step, gnorm=gn, clip=0.25)
         assert relerr(pd, p["w"]) < 1e-6
         assert relerr(pb, p["w"]) < 5e-3
+    # the kernels move 16 bytes per lane: a misaligned view is refused, not mis-read
+    with pytest.raises(Exception):
+        o.adam_step(pd[1:], gd[1:], m[1:], v[1:], None, 1e-2, 1)
 
 
 def test_transposes():
