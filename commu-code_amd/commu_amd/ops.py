@@ -776,7 +776,7 @@ def relattn_bwd(q, k, v, rd, u, vb, reset, T, M, B, H, DH, same_length, mem_len,
     if DELTA_KERNEL or o.stride(0) != dout.stride(0):
         call("commu_attn_delta", _p(o), _p(dout), o.stride(0), _p(delta), T, B, H, DH, _s())
     # fused band pass (commu_relattn_bwd_band: dq_BD and dRd in ONE sweep over dS-by-distance) when the shape allows
-    band_slabs = call("commu_attn_band_slabs", T, B) if (DH == 64 and K <= 4096 and not NO_FUSED_BAND) else 0
+    band_slabs = call("commu_attn_band_pairs", T, B, H) if (DH == 64 and K <= 4096 and not NO_FUSED_BAND) else 0
     ld_dsk = round_up(K, 128) if band_slabs else round_up(K, 32)
     # dS by distance is lower-triangular (d <= i + M).  Without same_length / reset masks the two GEMMs below only
     # visit the band (half the work) and the kernel only writes the triangle.  What lies right of the causal edge

@@ -267,11 +267,19 @@ extern "C" int commu_attn_band_slabs(int T, int B) {
     return 32;
 }
 
+extern "C" int commu_attn_band_pairs(int T, int B, int H) {
+    // H * P workgroups (one per CU: 160 KB of LDS) fill the chip once; every workgroup flushes a [K x 64] fp32 slab, so more
+    // pairs than that only add slab bytes (16 heads: 32 pairs wrote 0.54 GB per layer at K = 4096, 16 pairs write half)
+    if (commu_attn_band_slabs(T, B) == 0 || H <= 0) return 0;
+    const int P = 256 / H;
+    return P < 1 ? 1 : (P > 32 ? 32 : P);
+}
+
 extern "C" int commu_relattn_bwd_band(const void* dsk, int ld_dsk, const void* rd, int ld_rd, const void* qv2, int ld_qv,
                                       const void* dq_ac, int ld_ac, void* dq, int ld_dq, float* slabs, int T, int M,
                                       int B, int H, int DH, int band, hipStream_t stream) {
     const long long TB = (long long)T * B;
-    const int K = T + M, P = commu_attn_band_slabs(T, B);
+    const int K = T + M, P = commu_attn_band_pairs(T, B, H);
     if (P == 0 || DH != 64 || K > KMAX || ld_dsk < K || (ld_dsk % 128) || (ld_rd % 8) || (ld_qv % 8) || (ld_ac % 4) ||
         (ld_dq % 4) || (size_t)TB * ld_dsk * 2 >= 0x7FFF0000ull)
         return -22;

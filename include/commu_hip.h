@@ -368,14 +368,18 @@ int commu_relattn_bwd_q(const commu_attn_desc* d, const commu_attn_bwd_desc* e, 
 int commu_relattn_bwd_kv(const commu_attn_desc* d, const commu_attn_bwd_desc* e, hipStream_t stream);
 /* The two per-head GEMMs above fused into ONE pass over dsk (band.hip): dq = dq_ac + dsk . Rd (bf16, written in
  * place with row stride ld_dq) and slabs[(h * P + p)][Kp][64] = partial dsk^T . qv2 of token-slice pair p, with
- * P = commu_attn_band_slabs(T, B) and Kp = T + M rounded up to 512 (the kernel runs one pass per 512 distances,
+ * P = commu_attn_band_pairs(T, B, H) and Kp = T + M rounded up to 512 (the kernel runs one pass per 512 distances,
  * keeping that part of Rd resident in LDS); the caller finishes with
  *   commu_reduce_slabs2d_f32(dRd, ld, 64, slabs, K, 64, P, Kp * 64, H, 0, 1 / (scale * log2 e)).
  * dsk must be TILED (commu_attn_bwd_desc.dsk_tiled).  Needs DH == 64, T + M <= 4096, ld_dsk % 128 == 0, (T * B) % 64 == 0
  * and >= 8192 (else -22: use the two GEMMs on a row-major dsk).
  * band != 0: rows are causal (see commu_gemm_nt_bf16_batched, tri_B = B, tri_M = M) and only the chunks of 256
- * distances that reach the causal edge are read; what lies beyond the edge inside them must be zero. */
+ * distances that reach the causal edge are read; what lies beyond the edge inside them must be zero.
+ * commu_attn_band_pairs: token-slice pairs per head = min(32, 256 / H) -- H * P workgroups fill the 256 CUs once; with 16
+ * heads, 16 pairs write half the slab bytes of 32 -- 0: shape not taken.  commu_attn_band_slabs(T, B) = its upper bound 32
+ * (or 0), for callers that size a buffer before the head count is known. */
 int commu_attn_band_slabs(int T, int B);
+int commu_attn_band_pairs(int T, int B, int H);
 int commu_relattn_bwd_band(const void* dsk, int ld_dsk, const void* rd, int ld_rd, const void* qv2, int ld_qv,
                            const void* dq_ac, int ld_ac, void* dq, int ld_dq, float* slabs, int T, int M, int B,
                            int H, int DH, int band, hipStream_t stream);

@@ -641,6 +641,10 @@ ATTN_CASES = [
     # default shape tgt_len 128 / mem_len 1024, and a masked variant)
     (128, 1024, 64, 1, 64, False, 1024, None),
     (128, 1100, 64, 1, 64, True, 1100, 2),
+    # more than 8 heads: the band pass takes 256 / H token-slice pairs per head (25 pairs = 50 slices of 3 steps for 128
+    # steps: the last slices are empty; 16 pairs with memory)
+    (128, 0, 64, 10, 64, False, 0, None),
+    (64, 64, 128, 16, 64, False, 64, None),
 ]
 
 
