@@ -23,6 +23,7 @@
 // sums, and dS indexed by distance for the dR / dq_BD GEMMs), relattn_bwd_kv (kv-stationary: dk,
 // dv), attn_delta, transpose_heads.
 #include "relattn_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -1430,8 +1431,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int it = it_lo; it <= it_hi; ++it) {
-        const int i0 = it * 64, cur = (it - it_lo) & 1;
+    // (the step body is instantiated for each of the two buffer sets: with the buffer index a compile-time constant every LDS
+    //  address of the step is one per-lane base + an immediate -- a third of the step's vector instructions were address
+    //  arithmetic on the runtime buffer index)
+    auto step = [&](int it, auto curc) {
+        constexpr int cur = decltype(curc)::value;
+        const int i0 = it * 64;
         const bf16* sQu = sQu2[cur];
         const bf16* sdO = sdO2[cur];
         const float* sRs = sRs2[cur];
@@ -1494,6 +1499,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // the next step's tiles have landed (and its P values: they have had this step's arithmetic to arrive)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+    for (int it = it_lo; it <= it_hi; it += 2) {
+        step(it, std::integral_constant<int, 0>{});
+        if (it + 1 <= it_hi) step(it + 1, std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
