@@ -258,14 +258,15 @@ def decode_cpu_baseline(args, steps=256):
 
 
 def kernel_source_hash():
-    """sha256 over the attention kernel sources: the PMC traffic numbers are only valid for the code they were
-    measured on (tests/probes/pmc_traffic.py stamps the same hash into the profile)."""
-    import hashlib
-    h = hashlib.sha256()
-    for name in ("relattn.hip", "relattn3.hip", "band.hip", "gemm8.hip", "relattn_common.h", "common.h"):
-        with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()
+    """Stamp of the code the committed PMC profiles must have been measured on (commu_amd/source_stamp.py: every kernel source and
+    header, ops.py, model.py); the probes that write the profiles stamp the same value."""
+    from commu_amd import source_stamp
+    return source_stamp.kernel_source_hash()
+
+
+def traffic_switches():
+    from commu_amd import source_stamp
+    return source_stamp.traffic_switches()
 
 
 def pmc_traffic(kernel, args):
@@ -276,8 +277,10 @@ def pmc_traffic(kernel, args):
     import glob
     shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // passes_of(args)]
     try:
-        sha = kernel_source_hash()
+        sha, sw = kernel_source_hash(), traffic_switches()
     except OSError:
+        return None
+    if sw["FWD_SAVES_P"]:          # (the profiles are measured on the default path)
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
@@ -285,7 +288,7 @@ def pmc_traffic(kernel, args):
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
-        if rec.get("shape") == shape and rec.get("source_sha256") == sha:
+        if rec.get("shape") == shape and rec.get("source_sha256") == sha and rec.get("switches") == sw:
             return rec.get("bytes_per_launch", {}).get(kernel)
     return None
 
@@ -297,8 +300,10 @@ def step_traffic(args):
     import glob
     shape = [args.layers, args.d_model, args.heads, args.tgt_len, args.mem_len, args.batch_per_gpu // passes_of(args)]
     try:
-        sha = kernel_source_hash()
+        sha, sw = kernel_source_hash(), traffic_switches()
     except OSError:
+        return None
+    if sw["FWD_SAVES_P"]:          # (the profiles are measured on the default path)
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.json")), reverse=True):
         try:
@@ -306,7 +311,7 @@ def step_traffic(args):
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
-        if rec.get("shape") == shape and rec.get("source_sha256") == sha:
+        if rec.get("shape") == shape and rec.get("source_sha256") == sha and rec.get("switches") == sw:
             top = list(rec.get("kernels", {}).items())[:3]
             return {"bytes": rec.get("step_hbm_bytes"), "profile": os.path.basename(path),
                     "largest_movers": {k[:60]: round(v["bytes_per_step"] / 1e9, 3) for k, v in top}}
@@ -379,18 +384,12 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
 
     def run(nsteps, base, sample_events=False):
         for i in range(nsteps):
-            if sample_events:          # HIP events around the profiled entry points on every fourth step only
-                _lib.profile_enable(i % 4 == 0)
-                # (hipGraph mode: a replay has no per-call hooks, so the sampled steps run EAGERLY -- same kernels, same
-                #  streams -- and the other three quarters of the timed region are graph replays)
-                trainer.graph_mode = use_graph and i % 4 != 0
             d, t, r, n = batches[(base + i) % len(batches)]
             if step_log is not None:
                 th = time.perf_counter()
             trainer.step(d, t, r, n)
             if step_log is not None:
                 step_log.append(round(1e3 * (time.perf_counter() - th), 2))
-        trainer.graph_mode = use_graph
 
     run(warmup, 0)
     if use_graph:
@@ -403,14 +402,9 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    prof_names = ["commu_relattn_bwd_kv", "commu_relattn_bwd_q", "commu_relattn_fwd", "commu_relattn_fwd_save", "commu_gemm_nt_bf16",
-                  "commu_gemm_tn_bf16", "commu_gemm_tn_bf16_grouped", "commu_relattn_bwd_band"]
-    # (an event pair around every profiled call costs ~4 % of a step -- ~130 calls -- so only every fourth step of the
-    #  timed region is instrumented; time_share scales the sampled sums back to the whole region)
-    _lib.profile_start(prof_names, shape_args={"commu_gemm_nt_bf16": (6, 7, 8)})          # (M, N, K) of every NT GEMM
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(steps, warmup, sample_events=True)
+    run(steps, warmup)          # the timed region: nothing but the K optimiser steps (no event pairs, no hooks)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -421,20 +415,32 @@ def train_bench(args, dev, world, rank, steps, warmup, reset_prob=0.0):
               f"host ms per step() {step_log}; gc (step, generation, ms) {[g for g in gc_log if g[2] >= 1.0]}; reserved {ms['reserved_bytes.all.current'] >> 20} MiB, segments "
               f"{ms['segment.all.allocated']}, retries {ms['num_alloc_retries']}", file=sys.stderr, flush=True)
         gc.callbacks.remove(_gc_cb)
-    prof = _lib.profile_stop()
     LAST_COMM.clear()
     if reducer is not None:
         # attribution for the scaling curve: wire bytes per rank and step, and the time the main stream sat in
         # GradReducer.finish() waiting for the last bucket (the part of the exchange the backward pass did not hide)
         LAST_COMM.update(reducer.comm_stats(last=steps))
+    # Per-kernel HIP-event times come from SEPARATE steps right after the timed region (same trainer, same batches, same
+    # streams): an event pair around each of the ~130 profiled calls costs ~4 % of a step, which used to sit inside the
+    # number the driver reports (every fourth step).  hipGraph mode: a replay has no per-call hooks, so these steps run
+    # eagerly -- same kernels, same streams.
+    prof_names = ["commu_relattn_bwd_kv", "commu_relattn_bwd_q", "commu_relattn_fwd", "commu_relattn_fwd_save", "commu_gemm_nt_bf16",
+                  "commu_gemm_tn_bf16", "commu_gemm_tn_bf16_grouped", "commu_relattn_bwd_band"]
+    nprof = max(2, (steps + 3) // 4)
+    _lib.profile_start(prof_names, shape_args={"commu_gemm_nt_bf16": (6, 7, 8)})          # (M, N, K) of every NT GEMM
+    _lib.profile_enable(True)
+    trainer.graph_mode = False
+    run(nprof, warmup + steps)
+    torch.cuda.synchronize()
+    trainer.graph_mode = use_graph
+    prof = _lib.profile_stop()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     del trainer, model, batches
     torch.cuda.empty_cache()
-    sampled = len(range(0, steps, 4))
-    return elapsed, tokens_per_step, prof, steps / sampled
+    return elapsed, tokens_per_step, prof, steps / nprof
 
 
 def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
@@ -478,12 +484,12 @@ def attention_roofline(args, prof, tokens_per_step, elapsed, pscale=1.0):
                          "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "products": "dP = dO.V^T and dq = dS.K"},
                 "why_hbm": "the forward pass saves its probabilities: this kernel recomputes no scores (2 of the former 4 "
                            "products) and streams ~2 GB per launch",
-                "time_share": share, "event_sampling": "every 4th step of the timed region"}
+                "time_share": share, "event_sampling": "separate eager steps right after the timed region (max(2, K/4) of them)"}
     traffic = pmc_traffic(dom, args)
     out = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
            "flops_per_launch": fl_launch, "avg_launch_ms": round(avg_ms, 4), "launches": cnt[dom],
-           "time_share": share, "event_sampling": "every 4th step of the timed region"}
+           "time_share": share, "event_sampling": "separate eager steps right after the timed region (max(2, K/4) of them)"}
     if traffic:          # the same launch against the OTHER roof: measured HBM bytes / this run's launch time
         gbs = traffic / (avg_ms * 1e-3) / 1e9
         out["hbm_view"] = {"measured_traffic_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
@@ -731,7 +737,7 @@ def main():
                    "global_batch": B * world, "batch_per_gpu": B, "batch_chunk": args.batch_chunk,
                    "passes_per_step": passes_of(args), "seq_len": T,
                    "dropout": args.dropout, "parallelism": f"dp{world}", "optimizer": "clip1.0+Adam+invsqrt-LR",
-                   "launch": ("hipGraph replay (every 4th timed step eager, for the per-kernel events)"
+                   "launch": ("hipGraph replay (the per-kernel events come from eager steps after the timed region)"
                               if (args.graph if args.graph is not None else auto_graph(args)) else "eager"),
                    "weights": "random init (train.py:291-342)"},
         "step_tflops_algorithmic": round(step_flops / 1e12, 3),

@@ -133,8 +133,8 @@ def attn_fwd_generation(gen: int) -> int:
 
 
 def attn_bwd_kv_generation(gen: int) -> int:
-    """commu_attn_bwd_kv_generation: 0 automatic, 2 / 3 force a key-stationary backward kernel for d_head 64 with stored
-    probabilities; returns the previous value."""
+    """commu_attn_bwd_kv_generation: 0 automatic; 2 / 3 force a key-stationary backward kernel for d_head 64 with stored
+    probabilities; 4: both backward kernels on the 32x32 MFMA (relattn_q3.hip + relattn_kv3.hip); returns the previous value."""
     return call("commu_attn_bwd_kv_generation", int(gen))
 
 

@@ -1602,10 +1602,11 @@ extern "C" long long commu_attn_p_scratch_elems(int T, int M, int B, int H) {
 }
 
 constexpr bool KV3_DEFAULT = false;          // the automatic choice (generation 0)
+constexpr bool Q3_DEFAULT = false;           // generation 0 takes the 32x32-layout pair (relattn_q3.hip + relattn_kv3.hip, p_layout 2)
 static int g_kv_gen = 0;
 extern "C" int commu_attn_bwd_kv_generation(int gen) {
     const int prev = g_kv_gen;
-    if (gen == 0 || gen == 2 || gen == 3) g_kv_gen = gen;
+    if (gen == 0 || gen == 2 || gen == 3 || gen == 4) g_kv_gen = gen;
     return prev;
 }
 
@@ -1709,6 +1710,18 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
     if (a.pbuf != nullptr) {          // the query-stationary kernel stores P, the key-stationary one reads it back
         // (commu_attn_bwd_kv_generation: 3 = relattn_kv3.hip, 32 keys per wave on the 32x32 MFMA; the two launches of a
         //  backward pass must see the same setting -- it fixes the block order of the P scratch)
+        // generation 4: the query-stationary kernel of relattn_q3.hip (32 query rows per wave on the 32x32 MFMA, transposed
+        // scores) with relattn_kv3.hip reading its block order (p_layout 2)
+        if ((g_kv_gen == 4 || (Q3_DEFAULT && g_kv_gen == 0)) && relattn_bwd_q3_takes(a)) {
+            a.p_layout = 2;
+            if (which & 1) {
+                const int rc = launch_relattn_bwd_q3(a, stream);
+                if (rc != 0) return rc;
+            }
+            if (which & 2) launch_relattn_bwd_kv3(a, stream);
+            COMMU_LAUNCH_CHECK();
+            return 0;
+        }
         const bool kv3 = KV3_DEFAULT ? g_kv_gen != 2 : g_kv_gen == 3;
         a.p_layout = kv3 ? 1 : 0;
         const bool fromp = a.pf != nullptr;          // probabilities saved by the forward pass: no score recomputation

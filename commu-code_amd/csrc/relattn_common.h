@@ -35,7 +35,8 @@ struct AttnArgs {
     // that m for the 32 queries (fp32).  P = |e| * exp2(m - lse * log2 e).
     void* pf;
     int p_layout;       // 0: the block order above; 1: [B*H][ceil(T/32)][2 ceil(K/64)] blocks of [32 keys][2 halves][4][4 queries],
-                        //    the accumulator order of relattn_bwd_kv3_kernel
+                        //    the accumulator order of relattn_bwd_kv3_kernel; 2: the same block grid in the accumulator order of
+                        //    relattn_bwd_q3_kernel (lane (query, half), registers 8k .. 8k+7 at 1024 k + 16 (query + 32 half))
     int ld_qkv, ld_rd, ld_o, ld_dqkv, ld_dsk;
     int dsk_wedge;      // > 0: dsk is uninitialised; zero columns i+M+1 .. i+M+dsk_wedge of every row (band GEMM contract)
     int dsk_tiled;      // != 0: dsk is stored as [H][T*B/64][ld_dsk/128] tiles of [64 rows][128 distances] (band.hip)
@@ -50,6 +51,9 @@ struct AttnArgs {
 int launch_relattn_fwd3(const AttnArgs& a, hipStream_t stream);
 // relattn_kv3.hip (d_head 64): key-stationary backward from stored probabilities (p_layout 1) on the same MFMA
 int launch_relattn_bwd_kv3(const AttnArgs& a, hipStream_t stream);
+// relattn_q3.hip (d_head 64): query-stationary backward on the 32x32 MFMA / transposed-score layout; stores P in p_layout 2
+bool relattn_bwd_q3_takes(const AttnArgs& a);
+int launch_relattn_bwd_q3(const AttnArgs& a, hipStream_t stream);
 
 constexpr int PF_TILE_BYTES = 2176;
 

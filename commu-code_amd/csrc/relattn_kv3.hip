@@ -34,10 +34,16 @@ __device__ __forceinline__ void lds_dma4(srd_t srd, unsigned voff, unsigned lds_
 
 constexpr int TILEB = 8192;          // one [64 q][64 f] bf16 tile
 
-template <bool DROP>
+// P2 (AttnArgs.p_layout 2, written by relattn_bwd_q3_kernel): a block holds [32 queries x 32 keys] in the QUERY-stationary
+// kernel's accumulator order -- lane (query, half) of that kernel wrote its registers 8k .. 8k+7 (keys 16k + 8qq + 4 half + 3 - e) as
+// the 16 bytes at 1024 k + 16 (query + 32 half).  Here the lane is the KEY: a wave brings its block to a private 2-KB LDS image by
+// two LDS-DMA instructions (slot 4 query + 2 half + k, so that the reads below are conflict-free) and fetches the 16 queries of
+// its key with four ds_read_b64_tr_b16; the transpose hands lane l the key (l & 31) ^ 3 of the block (the quads are stored
+// reversed), so the V^T fragments and the dk / dv rows use that key order too.
+template <bool DROP, bool P2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void relattn_bwd_kv3_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * TILEB + 2 * 256];          // dO x2, (q+u) x2, delta x2
-    constexpr int OFF_O = 0, OFF_Q = 2 * TILEB, OFF_D = 4 * TILEB;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TILEB + 2 * 256 + (P2 ? 4 * 4096 : 0)];          // dO x2, (q+u) x2, delta x2, P blocks
+    constexpr int OFF_O = 0, OFF_Q = 2 * TILEB, OFF_D = 4 * TILEB, OFF_P = 4 * TILEB + 512;
     const LDS_AS char* lds = (const LDS_AS char*)smem;
     const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
 
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         // V^T fragments: lane key ii holds V[key][16 ks + 8 half .. + 8]
         bf16x8 vf[4];
         {
-            const int j = jw + ii;
+            const int j = jw + (P2 ? (ii ^ 3) : ii);
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             const size_t off = ((size_t)min(j, K - 1) * B + b) * a.ld_qkv + h * 64;
 #pragma unroll
@@ -140,9 +146,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 pn[qb][1] = ld_bf16x8(p + 8);
             }
         };
+        // P2: block (qs, ks32) of this wave -> its LDS image (one per query half qb); lane l of DMA instruction j fills slot
+        // 64 j + l = 4 query + 2 half + k from the block's piece 1024 k + 16 (query + 32 half)
+        const srd_t srdPB = make_srd((const char*)a.pbuf + bh * (size_t)QS * KS32 * 2048, P2 ? (size_t)QS * KS32 * 2048 : 0);
+        unsigned pvo[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int slot = 64 * j + lane;
+            pvo[j] = (unsigned)((slot & 1) * 1024 + ((slot >> 2) + 32 * ((slot >> 1) & 1)) * 16);
+        }
+        auto pdma = [&](int it, int qb) {          // (a block past the end lies beyond the descriptor: zeros)
+            const unsigned so = (unsigned)(((2 * it + qb) * KS32 + (jw >> 5)) << 11);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                lds_dma16s(srdPB, pvo[j], so, lds0 + (unsigned)(OFF_P + w * 4096 + qb * 2048 + j * 1024));
+        };
+        // transpose read of register quad q4 (queries 8 q4 + 4 half + 0..3) of the lane's key: the 16 lanes of a group supply
+        // the addresses of 4 queries x 4 key quads; key quad G = (r16 & 3) + 4 ((lane >> 4) & 1) sits in piece k = G >> 2 of the
+        // query-kernel lane (query, G & 1), at byte 8 ((G >> 1) & 1) of its 16
+        int pta[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int rho = 8 * q4 + 4 * half + (r16 >> 2), G = (r16 & 3) + 4 * ((lane >> 4) & 1);
+            pta[q4] = OFF_P + w * 4096 + (4 * rho + 2 * (G & 1) + (G >> 2)) * 16 + 8 * ((G >> 1) & 1);
+        }
         if (it_lo <= it_hi) {
             stage(it_lo, 0);
-            pfetch(it_lo);
+            if (P2) { pdma(it_lo, 0); pdma(it_lo, 1); }
+            else pfetch(it_lo);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -150,20 +181,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             const int buf = (it - it_lo) & 1, i0 = it * 64;
             bf16x8 px[2][2];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) { px[qb][0] = pn[qb][0]; px[qb][1] = pn[qb][1]; }
+            for (int qb = 0; qb < 2; ++qb) {
+                if (!P2) { px[qb][0] = pn[qb][0]; px[qb][1] = pn[qb][1]; }
+            }
             if (it < it_hi) {
                 stage(it + 1, buf ^ 1);
-                pfetch(it + 1);
+                if (!P2) pfetch(it + 1);
             }
             // the key tiles bwd_q visited (and stored P for) from this query step
             int jlo64, jhi64;
-            kv_range(a, i0, 64, rst, jlo64, jhi64);
+            kv_range(a, P2 ? (i0 & ~127) : i0, P2 ? 128 : 64, rst, jlo64, jhi64);
             const bool seen = jw < K && jt64 >= jlo64 && jt64 <= jhi64;
             const int tO = OFF_O + buf * TILEB, tQ = OFF_Q + buf * TILEB;
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int iq = i0 + 32 * qb;
-                if (!seen || iq >= T) continue;
+                // (P2: the query-stationary kernel visits the 32-key sub-tiles up to the last key its 32 rows can see)
+                const bool seen_qb = seen && iq < T && (!P2 || jw <= min(K - 1, min(iq + 31, T - 1) + M));
+                if (P2) {
+                    if (seen_qb) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const bf16x4 v4 = tr8(pta[q4] + qb * 2048);
+                            px[qb][q4 >> 1][4 * (q4 & 1) + 0] = v4[0]; px[qb][q4 >> 1][4 * (q4 & 1) + 1] = v4[1];
+                            px[qb][q4 >> 1][4 * (q4 & 1) + 2] = v4[2]; px[qb][q4 >> 1][4 * (q4 & 1) + 3] = v4[3];
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    if (it < it_hi) pdma(it + 1, qb);          // (this half's image is free again: single-buffered per wave)
+                }
+                if (!seen_qb) continue;
                 // -delta / dsc as the initial value of the dP accumulator (C layout: register r is query 8 (r >> 2) + 4 half + (r & 3))
                 f32x16 ndl;
 #pragma unroll
@@ -182,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float x = bf2f(px[qb][r >> 3][r & 7]);          // +-P scale/(1-p), negative: dropped (bwd_q)
-                    if (vrows < 32 && 8 * (r >> 2) + 4 * half + (r & 3) >= vrows) x = 0.f;
+                    if (!P2 && vrows < 32 && 8 * (r >> 2) + 4 * half + (r & 3) >= vrows) x = 0.f;          // (P2: whole blocks are written, rows beyond T as zeros)
                     const float p = DROP ? __builtin_fabsf(x) : x;
                     float pd = p, dpe = dp[r];
                     if (DROP) {
@@ -208,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         // accumulators: column = feature 32 dt + ii, register r = key jw + (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = jw + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int j = jw + (P2 ? 3 - (r & 3) : (r & 3)) + 8 * (r >> 2) + 4 * half;
             if (j < K) {
                 const size_t off = ((size_t)j * B + b) * a.ld_dqkv + h * 64 + ii;
 #pragma unroll
@@ -227,7 +274,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 int launch_relattn_bwd_kv3(const AttnArgs& a, hipStream_t stream) {
     const int K = a.T + a.M, NT = (K + 127) / 128;
     const dim3 grid(((NT + 1) / 2) * a.H * a.B);
-    if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true>), grid, dim3(256), 0, stream, a);
-    else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false>), grid, dim3(256), 0, stream, a);
+    if (a.p_layout == 2) {
+        if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, true>), grid, dim3(256), 0, stream, a);
+        else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, true>), grid, dim3(256), 0, stream, a);
+        return 0;
+    }
+    if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, false>), grid, dim3(256), 0, stream, a);
+    else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, false>), grid, dim3(256), 0, stream, a);
     return 0;
 }

@@ -318,8 +318,10 @@ long long commu_attn_pf_bytes(int T, int M, int B, int H);
  * kernel -- both forward generations and the backward family -- regenerates the same dropout mask (relattn.hip DropLane: one
  * mixed word per 2x2 cell of a 32x32 block, one multiply-add per element), so any forward pairs with the backward. */
 int commu_attn_fwd_generation(int gen);
-/* Key-stationary backward kernel for d_head 64 with a P scratch (process-wide; returns the previous value).  3: relattn_kv3.hip
- * (32 keys per wave on the 32x32 MFMA); 2: the 16x16-layout kernel; 0: the build's default.  The setting fixes the block order in
+/* Backward kernel pair for d_head 64 with a P scratch (process-wide; returns the previous value).  3: relattn_kv3.hip
+ * (32 keys per wave on the 32x32 MFMA) behind the 16x16 query-stationary kernel; 4: both kernels on the 32x32 MFMA
+ * (relattn_q3.hip: 32 query rows per wave, transposed scores; relattn_kv3.hip transposes its P blocks through LDS);
+ * 2: the 16x16-layout pair; 0: the build's default.  The setting fixes the block order in
  * which commu_relattn_bwd_q writes the scratch: both launches of a backward pass must see the same value. */
 int commu_attn_bwd_kv_generation(int gen);
 

@@ -33,11 +33,14 @@ drd = torch.zeros(K, HD, device=dev)
 du, dvb = torch.zeros(HD, device=dev), torch.zeros(HD, device=dev)
 
 
+SCR = {} if os.environ.get("AB_SCRATCH", "1") != "0" else None          # persistent zero-initialised dS scratch, like the model
+
+
 def run():
     out, lse, qs = ops.relattn_fwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, save_q=True, save_p=True, drop_p=DROP, drop_seed=1234)
     if "bwd" in WHAT:
         ops.relattn_bwd(q, k, v, rd, u, vb, None, T, M, B, H, DH, False, M, out, dout, lse, qs, dqkv[M * B:, :HD],
-                        dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=DROP, drop_seed=1234)
+                        dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb, drop_p=DROP, drop_seed=1234, scratch=SCR)
 
 
 run()

@@ -29,11 +29,9 @@ def per_launch(db, counter):
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sha = hashlib.sha256()
-for name in ("relattn.hip", "relattn3.hip", "band.hip", "gemm8.hip", "relattn_common.h", "common.h"):          # the same hash bench.py computes: a stale profile is refused
-    with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
-        sha.update(f.read())
-out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": sha.hexdigest(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+sys.path.insert(0, os.path.join(ROOT, "commu-code_amd"))
+from commu_amd import source_stamp          # the same stamp bench.py computes: a stale profile is refused
+out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": source_stamp.kernel_source_hash(), "switches": source_stamp.traffic_switches(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
        "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-extra`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB",
        "fetch_kib_raw": {KERNELS[k]: fetch[k] for k in fetch}, "write_kib_raw": {KERNELS[k]: write[k] for k in write},
        "bytes_per_launch": {KERNELS[k]: (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024.0 for k in fetch}}

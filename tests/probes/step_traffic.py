@@ -79,11 +79,9 @@ for k in set(fetch) | set(write):
 order = sorted(rows, key=lambda k: -rows[k]["bytes_per_step"])
 total = sum(r["bytes_per_step"] for r in rows.values())
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sha = hashlib.sha256()
-for name in ("relattn.hip", "relattn3.hip", "band.hip", "gemm8.hip", "relattn_common.h", "common.h"):
-    with open(os.path.join(ROOT, "commu-code_amd", "csrc", name), "rb") as f:
-        sha.update(f.read())
-out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": sha.hexdigest(), "steps_in_run": steps,
+sys.path.insert(0, os.path.join(ROOT, "commu-code_amd"))
+from commu_amd import source_stamp          # the same stamp bench.py computes: a stale profile is refused
+out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": source_stamp.kernel_source_hash(), "switches": source_stamp.traffic_switches(), "steps_in_run": steps,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python3 bench.py --steps 4 "
                  "--warmup 2 --no-cpu-baseline --no-decode --no-extra`; bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, summed over every "
                  "dispatch of the run and divided by its optimiser steps (the first step's one-off initialisation included)",
