@@ -65,6 +65,7 @@ PROTOTYPES = {
     "commu_gemm_tn_bf16_batched": [c_p, c_i, C.c_longlong, c_p, c_i, C.c_longlong, c_p, c_i, c_z, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_i, c_p],
     "commu_gemm_tn_grouped_slices": [C.POINTER(TnProblem), c_i, c_i],
+    "commu_gemm_tn_grouped_slices_budget": [C.POINTER(TnProblem), c_i, c_i, c_i],
     "commu_gemm_tn_bf16_grouped": [C.POINTER(TnProblem), c_i, c_i, c_p, C.c_longlong, c_i, c_p],
     "commu_reduce_slabs2d_f32": [c_p, c_i, C.c_longlong, c_p, c_i, c_i, c_i, c_z, c_i, c_i, c_f, c_p],
     "commu_reduce_slabs_f32": [c_p, c_p, c_z, c_i, c_z, c_i, c_f, c_p],
@@ -157,7 +158,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"commu_decode_tail_pack_bytes": C.c_longlong, "commu_attn_pf_bytes": C.c_longlong, "commu_hip_version": C.c_char_p, "commu_attn_p_scratch_elems": C.c_longlong,
             "commu_gemm_nt_signbits_words": C.c_longlong, "commu_pack_batch": C.c_longlong}
-_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_attn_fwd_generation", "commu_attn_bwd_kv_generation", "commu_colsum_slab_pass", "commu_gemm_tn_grouped_slices", "commu_attn_band_slabs", "commu_attn_band_pairs",
+_NOCHECK = {"commu_layernorm_bwd_nblocks", "commu_colsum_slabs", "commu_embed_bwd_ws_rows", "commu_hip_version", "commu_attn_bwd_qrows", "commu_attn_fwd_generation", "commu_attn_bwd_kv_generation", "commu_colsum_slab_pass", "commu_gemm_tn_grouped_slices", "commu_gemm_tn_grouped_slices_budget", "commu_attn_band_slabs", "commu_attn_band_pairs",
             "commu_forcing_state_ints", "commu_decode_tail_supported", "commu_decode_tail_sync_words", "commu_decode_tail_pack_bytes", "commu_attn_p_scratch_elems", "commu_gemm_nt_signbits_words", "commu_pack_batch", "commu_attn_pf_bytes"}
 
 _lib = None

@@ -213,6 +213,17 @@ class MemTransformerLM(nn.Module):
     def forward(self, data, target, reset_mems, mems):                   # model.py:678-693
         if mems is None:
             mems = self.init_mems(self.n_layer)
+        if getattr(self, "parity_fp32", False):
+            # the reference's arithmetic (fp32 end to end, train.py:48 `amp = None`) for the LOSS of a forward pass --
+            # evaluate (train.py:74-110) and any no-grad forward; there is no fp32 backward pass
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()):
+                raise CommuHipError("parity_fp32 is a forward-only mode: call forward under torch.no_grad() (evaluate does), "
+                                    "or switch it off for training")
+            if self.training and (float(self.drop.p) > 0 or (self.n_layer > 0 and float(self.layers[0].dec_attn.dropatt.p) > 0)):
+                raise CommuHipError("parity_fp32 has eval-mode semantics (no dropout): call model.eval() first")
+            with torch.no_grad():
+                nll, new_mems, _ = self._run_forward_f32(data, mems, reset=reset_mems, target=target)
+            return nll, new_mems
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()):
             self._ensure_flat()
             loss, new_mems = _XLLoss.apply(self, data, target, reset_mems, mems, *self._flat["params"])
@@ -234,12 +245,14 @@ class MemTransformerLM(nn.Module):
             logits, new_mems, _ = self._run_forward(data, None, None, mems, need_grad=False, want_logits=True)
         return logits, new_mems
 
-    def _run_forward_f32(self, data, mems, want_kv=False):
+    def _run_forward_f32(self, data, mems, want_kv=False, reset=None, target=None):
         """forward_generate (model.py:606-628 -> _forward :576-604) in the reference's own arithmetic: fp32 master weights
         (no bf16 shadows, no padding), fp32 activations and memory, fp32 MFMA Linears, accurate transcendentals
         (csrc/parity_f32.hip).  The mode behind the "bit-exact greedy tokens" claim: `model.parity_fp32 = True` /
         `generate.py --parity`; what differs from the reference is summation order only.  Eval-mode semantics (no dropout),
-        memory as the reference keeps it: a fp32 [L+1, M, B, d_model] tensor."""
+        memory as the reference keeps it: a fp32 [L+1, M, B, d_model] tensor.
+        reset (optional bool [B]): `reset_mems` of forward (model.py:558-574: that sequence does not see the memory).
+        target (optional [T, B]): return the per-token NLL [T, B] (model.py:689-691, fp32 log-softmax) instead of the logits."""
         params = self._param_list()
         dev = params[0].device
         if dev.type != "cuda" or not data.is_cuda:
@@ -257,6 +270,9 @@ class MemTransformerLM(nn.Module):
         h = ops.embed_f32(data.contiguous().view(-1), E)                                   # model.py:585
         pd = ops.posemb_f32(self.pos_emb.inv_freq, K, D, clamp_len=int(self.clamp_len))    # :578-584 (by distance)
         u, vb = self.r_w_bias.contiguous(), self.r_r_bias.contiguous()
+        rst = None
+        if reset is not None and M > 0:
+            rst = reset.to(device=dev, dtype=torch.uint8).contiguous()
         hids = [h]
         kv_out = []
         for i in range(L):
@@ -269,7 +285,7 @@ class MemTransformerLM(nn.Module):
             ops.gemm_nt_f32(h, Wqkv, out=qkv[M * B:])
             rd = ops.gemm_nt_f32(pd, att.r_net.weight)                                     # :308-310
             vec = ops.relattn_f32(qkv[M * B:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:], B * 3 * HD, 3 * HD, rd, u, vb,
-                                  T, M, B, H, DH, bool(self.same_length), int(self.mem_len), self.attn_scale)
+                                  T, M, B, H, DH, bool(self.same_length), int(self.mem_len), self.attn_scale, reset=rst)
             z1 = ops.gemm_nt_f32(vec, att.o_net.weight, resid=h)                           # :344-349
             a = ops.layernorm_f32(z1, att.layer_norm.weight, att.layer_norm.bias, att.layer_norm.eps)
             hid = ops.gemm_nt_f32(a, ff.CoreNet[0].weight, bias=ff.CoreNet[0].bias, relu=True)     # :163-181
@@ -287,6 +303,9 @@ class MemTransformerLM(nn.Module):
             beg = max(0, end - self.mem_len)
             new_mems = allm[:, beg:end].contiguous()
         logits = ops.gemm_nt_f32(h, E, bias=self.crit.out_layers[0].bias)                  # :46,620-626 (tied weight)
+        if target is not None:                                                             # :689-691 (fp32 log-softmax + gather)
+            nll, _ = ops.ce_fwd(logits, target.contiguous().view(-1).to(dev), V)
+            return nll.view(T, B), new_mems, (kv_out if want_kv else None)
         return logits.view(T, B, V), new_mems, (kv_out if want_kv else None)
 
     def zero_grad(self, set_to_none: bool = True):                      # nn.Module.zero_grad without the module-tree walk
@@ -723,7 +742,9 @@ class MemTransformerLM(nn.Module):
         # stream between a defer() and the flush that follows it, so the later hand-over reads the same data.
         side_fns = []
 
-        def flush_wgrads():
+        def flush_wgrads(wide=False):
+            # wide: the launch may take every CU (the last one of the pass: the main stream has one GEMM and the embedding
+            # scatter left and then WAITS for it -- at half the chip it ended 0.25 ms after them, round-6 trace)
             if not pending and not side_fns:
                 return
             batch = list(pending)
@@ -739,7 +760,7 @@ class MemTransformerLM(nn.Module):
                 for it in batch:
                     groups.setdefault(it[0].shape[0], []).append(it)
                 for items in groups.values():
-                    self._tn_group_acc(items)
+                    self._tn_group_acc(items, budget=256 if wide else None)
             if side is None:
                 return run()
             ev = torch.cuda.Event()
@@ -921,7 +942,7 @@ class MemTransformerLM(nn.Module):
             wgrad(dqkv[M * B:], sv.h[i], gW, crop=spec("qkv"), colsum=None if hook_last else (gvb, HD))
             if M > 0:
                 wgrad(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
-            flush_wgrads()
+            flush_wgrads(wide=last and not getattr(self, "narrow_last_wgrad", False))          # (attribute: A/B runs only)
             dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
             hook = getattr(self, "grad_ready_hook", None)
             if hook is not None and direct:
@@ -967,12 +988,12 @@ class MemTransformerLM(nn.Module):
             return tuple(None for _ in params)
         return tuple(G[off:off + p.numel()].view(p.shape) for p, off in zip(params, fl["offs"]))
 
-    def _tn_group_acc(self, items):
+    def _tn_group_acc(self, items, budget=None):
         """items = [(dY, X, gW, rows, crop), ...] with a common token count: gW (+)= dY^T X for each, one grouped
         launch + one reduce per problem; falls back to _tn_acc when the grouped kernel does not take the shapes."""
         fl = self._flat
         arr, Mtok, offs, total, cs_offs = ops.tn_group([(it[0], it[1]) for it in items], colsum=[it[5] is not None for it in items])
-        ns = ops.tn_group_slices(arr, Mtok)          # (<= 8 problems; the reductions below go in launches of <= 8 destinations)
+        ns = ops.tn_group_slices(arr, Mtok, budget)          # (<= 8 problems; the reductions below go in launches of <= 8 destinations)
         if ns <= 0:
             for dY, Xa, gW, rows, crop, cs in items:
                 self._tn_acc(dY, Xa, gW, rows=rows, crop=crop)

@@ -294,8 +294,11 @@ def tn_group(pairs, colsum=None):
     return arr, M, offs, total, cs
 
 
-def tn_group_slices(arr, M):
-    """Token slices the grouped kernel wants for this group (0: not eligible -> per-problem commu_gemm_tn_bf16)."""
+def tn_group_slices(arr, M, budget=None):
+    """Token slices the grouped kernel wants for this group (0: not eligible -> per-problem commu_gemm_tn_bf16).
+    budget: workgroups the launch may take (default: the library's 128 = half of every XCD, for a launch beside the backward pass)."""
+    if budget is not None:
+        return _lib.load().commu_gemm_tn_grouped_slices_budget(arr, len(arr), int(M), int(budget))
     return _lib.load().commu_gemm_tn_grouped_slices(arr, len(arr), int(M))
 
 

@@ -976,6 +976,16 @@ static bool tn_group_plan(const commu_tn_problem* probs, int nprob, int M, Tn8Ar
     return true;
 }
 
+extern "C" int commu_gemm_tn_grouped_slices_budget(const commu_tn_problem* probs, int nprob, int M, int budget) {
+    Tn8Args a;
+    if (budget <= 0 || !tn_group_plan(probs, nprob, M, &a)) return 0;
+    int s = budget / a.total_tiles;
+    if (s >= 8) s &= ~7;
+    if (s < 1) s = 1;
+    const int cap = (M + 1023) / 1024;          // at least 16 K-tiles per workgroup
+    return s > cap ? cap : s;
+}
+
 extern "C" int commu_gemm_tn_grouped_slices(const commu_tn_problem* probs, int nprob, int M) {
     Tn8Args a;
     if (!tn_group_plan(probs, nprob, M, &a)) return 0;

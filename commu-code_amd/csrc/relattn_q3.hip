@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 4; ++q) ar[u][q] = rowb + 4 * (60 - ((32 * u + 8 * q + 4 * half - 4 * (ii >> 2)) & 63));
     // the wave's dS-by-distance ring: row ii at 128 ii, distance d at column d & 63
     const unsigned dsrow = lds0 + (unsigned)(OFF_DS + w * DSB + ii * 128);
+    const int dsflush = OFF_DS + w * DSB + (lane >> 1) * 128;          // flush: lane (row = lane >> 1, k = lane & 1)
 
     const unsigned key_bh = DROP ? mix32(salted(a.drop_seed) + (unsigned)(b * a.H + h) * 0x9E3779B1u) : 0u;
     const unsigned xl = (unsigned)(((ii >> 1) << 4) | (2 * half)) * DROP_C1;
@@ -197,32 +198,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int n = 0; n < 4; ++n) *(LDS_AS bf16x8*)(lds + OFF_DS + w * DSB + (lane + 64 * n) * 16) = z;
         }
-        // flush addressing of this tile: lane (row = (lane >> 2) + 16 n2, k = lane & 3) -> byte offset of its rows in this head's
+        // flush addressing of this tile: lane (row = lane >> 1, k = lane & 1) -> byte offset of its row in this head's
         // dS-by-distance block
-        unsigned fl_rows[2];
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-            const unsigned m = (ABL & 512) ? (unsigned)b * (unsigned)T + (unsigned)min(iw + (lane >> 2) + 16 * n2, T - 1)
-                                           : (unsigned)min(iw + (lane >> 2) + 16 * n2, T - 1) * (unsigned)B + (unsigned)b;
-            fl_rows[n2] = a.dsk_tiled ? (((m >> 6) * (unsigned)(a.ld_dsk >> 7)) << 14) + ((m & 63u) << 8) : m * (unsigned)a.ld_dsk * 2u;
+        const int fl_i = iw + (lane >> 1);
+        unsigned fl_row;
+        {
+            const unsigned m = (ABL & 512) ? (unsigned)b * (unsigned)T + (unsigned)min(fl_i, T - 1)          // (experiment: batch-major tiles)
+                                           : (unsigned)min(fl_i, T - 1) * (unsigned)B + (unsigned)b;
+            fl_row = a.dsk_tiled ? (((m >> 6) * (unsigned)(a.ld_dsk >> 7)) << 14) + ((m & 63u) << 8) : m * (unsigned)a.ld_dsk * 2u;
         }
-        auto dsk_off = [&](unsigned fl_row, int c) -> unsigned {  // byte offset of aligned chunk c (distances 8c .. 8c+7) of a row
+        auto dsk_off = [&](int c) -> unsigned {                   // byte offset of aligned chunk c (distances 8c .. 8c+7) of the lane's row
             return a.dsk_tiled ? fl_row + ((((unsigned)(c >> 4)) << 13) + (unsigned)((8 * c) & 127)) * 2u
                                : fl_row + (unsigned)(8 * c) * 2u;
         };
         if (rst && jt_lo > 0) {
-            // a sequence that starts here (reset_mems) skips its memory tiles: the distances above the first flushed segment, up
-            // to i + M, must still read as zero for the band consumers (the scratch is re-used between layers and steps)
+            // a sequence that starts here (reset_mems) skips its memory tiles: their distances (dtop, i + M] must still read as
+            // zero for the band consumers (the scratch is re-used between layers and steps), so they are written
+            const int dtop = fl_i + M - 64 * jt_lo, clast = (fl_i + M) >> 3;
             const u32x4 z4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const int i = iw + (lane >> 2) + 16 * n2;
-                const int dlo0 = i + M - 64 * jt_lo - 31, clast = (i + M) >> 3;
-                for (int c = 4 * (((dlo0 + 31) >> 5) + 1) + (lane & 3); c <= ((iw + 31 + M) >> 3); c += 4) {
-                    unsigned off = dsk_off(fl_rows[n2], c);
-                    if (!(i < T && c <= clast)) off = 0x80000000u;
-                    __builtin_amdgcn_raw_buffer_store_b128(z4, srdD, (int)off, 0, 0);
-                }
+            for (int c = (dtop >> 3) + 1 + (lane & 1); c <= ((iw + 31 + M) >> 3); c += 2) {
+                unsigned off = dsk_off(c);
+                if (!(fl_i < T && c <= clast)) off = 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(z4, srdD, (int)off, 0, 0);
             }
         }
         // P blocks of this wave's 32 rows: block (iw >> 5, ks32) at ((iw >> 5) KS32 + ks32) 2 KB of this (batch, head)'s part
@@ -324,18 +321,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){pw[4], pw[5], pw[6], pw[7]}, srdP, 1024 + lane * 16, so, 2);
             }
             __builtin_amdgcn_wave_barrier();
-            // flush: the sub-tile completed distances [i + M - jb - 31, ..).  Every row flushes ONE 64-byte-aligned segment of 32
-            // distances per step -- the segment 32 s with dlo <= 32 s < dlo + 32 (it lies inside the ring's 64-distance window) --
-            // as four 16-byte chunks from four consecutive lanes: one 64-byte write request per row instead of two 32-byte pieces
+            // flush: the sub-tile completed distances [i + M - jb - 31, ..): the 4 aligned chunks from c0 = ceil(that / 8), two
+            // lanes per row.  (Measured: ONE 64-byte-aligned segment of 32 distances per row and step from four lanes -- half the
+            // write requests -- is SLOWER, 765 against 650 us per launch; so is nothing about the tile order: batch-major tiles,
+            // where a wave's rows are neighbours in memory, measure the same.)
             if (!(ABL & 3)) {
+                const int dlo = fl_i + M - jb - 31;
+                const int cf = ((dlo + 7) >> 3) + (lane & 1);
 #pragma unroll
                 for (int n2 = 0; n2 < 2; ++n2) {
-                    const int row = (lane >> 2) + 16 * n2;
-                    const int dlo = iw + row + M - jb - 31;
-                    const int c = 4 * ((dlo + 31) >> 5) + (lane & 3);
-                    const bf16x8 v8 = *(const LDS_AS bf16x8*)(lds + OFF_DS + w * DSB + row * 128 + ((8 * c) & 63) * 2);
-                    unsigned off = dsk_off(fl_rows[n2], c);
-                    if (!(iw + row < T && c >= 0)) off = 0x80000000u;
+                    const int c = cf + 2 * n2;
+                    const bf16x8 v8 = *(const LDS_AS bf16x8*)(lds + dsflush + ((8 * c) & 63) * 2);
+                    unsigned off = dsk_off(c);
+                    if (!(fl_i < T && c >= 0)) off = 0x80000000u;
                     if (!(ABL & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v8), srdD, (int)off, 0, 0);
                 }
             }

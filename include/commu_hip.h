@@ -93,6 +93,10 @@ typedef struct commu_tn_problem {
 } commu_tn_problem;
 /* number of token slices that fills the 256 CUs for this group (0: a problem is not eligible) */
 int commu_gemm_tn_grouped_slices(const commu_tn_problem* probs, int nprob, int M);
+/* the same for a workgroup budget: tiles x slices <= budget (the default above is 128: the launch runs on the side stream
+ * beside the backward pass and leaves half of every XCD to it; the LAST launch of a pass, which the main stream ends up
+ * waiting for, takes 256) */
+int commu_gemm_tn_grouped_slices_budget(const commu_tn_problem* probs, int nprob, int M, int budget);
 int commu_gemm_tn_bf16_grouped(const commu_tn_problem* probs, int nprob, int M, float* slabs,
                                long long slab_stride, int nslices, hipStream_t stream);
 /* dst[z][r*ldd + c] = (accumulate ? dst : 0) + alpha * sum_s src[(z*nslabs + s)*stride + r*cols + c] */

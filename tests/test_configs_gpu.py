@@ -167,6 +167,52 @@ def test_bench_shape_full_batch_columns_vs_oracle():
     assert float(d.max()) < 3e-2 and float(d.mean()) < 3e-3, (float(d.max()), float(d.mean()))
 
 
+def test_bench_shape_full_batch_gradients_vs_oracle():
+    """The BACKWARD pass at the bench batch against the oracle.  With every target outside three columns set to pad (0),
+    loss[target != 0].mean() depends on those three columns only and -- the forward being column-independent -- EVERY
+    parameter gradient of the 64-column run must equal the oracle's gradient of the 3-column run (train.py:148-155), while
+    all kernels run their bench-size grids: grouped weight-gradient GEMMs over 65 536 rows, the band pass over 512 (batch,
+    head) pairs, the side-stream ordering, the embedding scatter over 65 536 tokens.  Bounds: those of
+    test_config_shape_loss_and_grads_vs_oracle."""
+    L, H, D, DI, T, B = 6, 8, 512, 1024, 1024, 64
+    model, cfg, s, params = build(L, H, D, DI, T, 0, seed=23)
+    model.eval()
+    g = torch.Generator().manual_seed(19)
+    data = torch.randint(1, 729, (T, B), generator=g)
+    full = torch.randint(1, 729, (T, B), generator=g)
+    cols = [0, 31, 63]
+    target = torch.zeros_like(full)
+    target[:, cols] = full[:, cols]
+    target[-7:, 31] = 0                                          # some pads inside a live column too
+    reset = torch.zeros(B, dtype=torch.bool)
+    model.zero_grad()
+    loss, _ = model(data.to(DEV), target.to(DEV), reset.to(DEV), None)
+    loss[target.to(DEV) != 0].float().mean().backward()
+    oparams = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    nll, _ = X.forward_loss(oparams, s, data[:, cols], target[:, cols], reset[cols], None, 0, False)
+    X.masked_mean_loss(nll, target[:, cols]).backward()
+    err = (loss.detach().float().cpu()[:, cols] - nll.detach()).abs()
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 8e-3, (float(err.max()), float(err.mean()))
+    cos, rel = {}, {}
+    for name, prm in model.named_parameters():
+        if name not in oparams or oparams[name].grad is None:
+            continue
+        a, b = prm.grad.detach().float().cpu().flatten(), oparams[name].grad.flatten()
+        assert bool(torch.isfinite(a).all()), name
+        cos[name] = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        rel[name] = float((a - b).norm() / (b.norm() + 1e-30))
+    assert len(cos) >= 3 + 11 * L
+    worst = sorted(cos.items(), key=lambda kv: kv[1])[:3]
+    print(f"bench batch: lowest gradient cosines {[(k, round(v, 5)) for k, v in worst]}; "
+          f"largest relative errors {[(k, round(v, 4)) for k, v in sorted(rel.items(), key=lambda kv: -kv[1])[:3]]}")
+    # measured (round 6): cosines >= 0.9994, relative errors <= 0.036 (worst: the first FFN Linear of layer 0, then r_net.weight)
+    bad = {k: v for k, v in cos.items() if v < 0.998}
+    assert not bad, bad
+    # (no column but the three may have contributed: the norms agree, not only the directions)
+    badn = {k: v for k, v in rel.items() if v > 0.06}
+    assert not badn, badn
+
+
 def test_bench_shape_full_batch_trains():
     """configs[1] at the bench batch (64 x 1024 tokens): finite loss that goes down over optimiser steps."""
     from commu_amd.model.config_helper import get_cfg

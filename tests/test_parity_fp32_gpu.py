@@ -292,3 +292,72 @@ def test_generate_cli_parity_flag(golden_dir, tmp_path):
         G.DecodeState.__init__ = orig_init
     assert built and all(built)
     assert outs[0] == outs[1] and outs[0]["encoded_meta"][0] == 574
+
+
+# ---------------------------------------------------------------------------------------------- forward (loss) / evaluate
+@pytest.mark.parametrize("tag", ["mem", "nomem", "dh50", "clamp"])
+def test_g1_loss_and_memory_fixtures_in_parity_mode(golden_dir, tag):
+    """model.parity_fp32 also serves forward() under no_grad (model.py:678-693: per-token NLL + new memory): the reference's
+    own outputs for three consecutive segments -- memory carried, a reset_mems column, pad tails, d_head 50, clamp_len 9 --
+    to fp32 summation-order accuracy (bf16 path: 4e-2 on the worst token)."""
+    from test_model_gpu import build_from_fixture
+    z = load(golden_dir, f"g1_train_{tag}.npz")
+    model, cfg = build_from_fixture(z)
+    model.eval()
+    model.parity_fp32 = True
+    mems = None
+    with torch.no_grad():
+        for seg in range(3):
+            data = torch.from_numpy(z[f"data{seg}"]).to(DEV)
+            target = torch.from_numpy(z[f"target{seg}"]).to(DEV)
+            reset = torch.from_numpy(z[f"reset{seg}"]).to(DEV)
+            loss, mems = model(data, target, reset, mems)
+            ref = torch.from_numpy(z[f"loss{seg}"])
+            assert loss.dtype == torch.float32 and tuple(loss.shape) == tuple(ref.shape)
+            err = float((loss.cpu() - ref).abs().max())
+            assert err < 1e-5 * float(ref.abs().max()), (tag, seg, err)          # per-token NLL ~ 6.6: <= 7e-5 absolute
+            if tag != "nomem":
+                assert mems.dtype == torch.float32 and mems.shape == z[f"mems{seg}"].shape
+                assert rel(mems, z[f"mems{seg}"]) < 1e-5, (tag, seg)
+            else:
+                assert mems is None
+            scalar = float(loss[target != 0].mean())
+            assert abs(scalar - float(z[f"scalar{seg}"])) < 1e-5 * abs(float(z[f"scalar{seg}"]))
+    # forward-only: a gradient-enabled call says so instead of silently leaving the mode
+    from commu_amd._lib import CommuHipError
+    with pytest.raises(CommuHipError):
+        model(data, target, reset, None)
+
+
+def test_evaluate_in_parity_mode_vs_oracle():
+    """Trainer.evaluate (train.py:74-110) with model.parity_fp32: same_length masks, the EVALUATE memory overflowing its window,
+    a memory reset between segments -- NLL per token within 1e-6 relative of the fp32 oracle (bf16 path: 6e-3 absolute)."""
+    from test_configs_gpu import build
+    from commu_amd.train import Trainer
+    L, H, D, DI, T, B = 2, 2, 100, 136, 48, 3
+    model, cfg, s, params = build(L, H, D, DI, T, 0, seed=31)
+    cfg.defrost() if hasattr(cfg, "defrost") else None
+    cfg.EVALUATE.tgt_length, cfg.EVALUATE.mem_length = T, 80
+    g = torch.Generator().manual_seed(12)
+    segs = []
+    for i in range(4):
+        data = torch.randint(1, 729, (T, B), generator=g)
+        target = torch.randint(1, 729, (T, B), generator=g)
+        target[-3:, 1] = 0
+        segs.append((data, target, i == 2, int((target != 0).sum())))
+
+    def eval_iter():
+        for d, t, r, n in segs:
+            yield d.to(DEV), t.to(DEV), r, n
+    model.parity_fp32 = True
+    tok, nll = Trainer(model, cfg).evaluate(eval_iter)
+    ref_tok, ref_nll, omems = 0, 0.0, None
+    with torch.no_grad():
+        for d, t, r, n in segs:
+            if r:
+                omems = None
+            loss, omems = X.forward_loss(params, s, d, t, None, omems, 80, True)
+            ref_nll += n * float(loss[t != 0].double().mean())
+            ref_tok += n
+    assert tok == ref_tok
+    assert abs(nll / tok - ref_nll / ref_tok) < 1e-6 * (ref_nll / ref_tok), (nll / tok, ref_nll / ref_tok)
