@@ -48,7 +48,11 @@ class GradReducer:
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._stream = None
         # RCCL reduces to the mean directly; gloo (CPU tests, or CUDA tensors staged through the host) has no AVG
-        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self._avg = self.backend == "nccl"
+        # gloo moves host memory only: device tensors (two test ranks on one GPU) are staged through the host
+        self._host_staged = self.backend == "gloo"
+        self._wire_buf = {}          # bf16 wire format: (elements, device) -> (send, recv, mean, out), allocated once per bucket size
         # exchange_single: run the whole exchange protocol (buckets, communication stream, collectives) in a group of
         # ONE rank too -- the mean over one rank is the identity, so this only exists to execute the RCCL path on a
         # single device (tests/test_ddp_gpu.py); a one-rank job otherwise skips the exchange.
@@ -60,6 +64,8 @@ class GradReducer:
 
     def _wire_bytes(self, n):
         w = max(self.world, 1)
+        if self.wire_dtype == "bf16":          # what is SENT: the zero-padded shards (w * ceil(n / w) elements)
+            n = w * ((n + w - 1) // w)
         return int(2 * (w - 1) / w * n * (2 if self.wire_dtype == "bf16" else 4))
 
     def _exchange(self, t, async_op):
@@ -72,17 +78,26 @@ class GradReducer:
         w = self.world
         n = t.numel()
         shard = (n + w - 1) // w
-        send = torch.zeros(w * shard, dtype=torch.bfloat16, device=t.device)
-        send[:n].copy_(t)
-        if t.is_cuda and not self._avg:
-            # gloo moves host memory only (two test ranks on one GPU): stage the bf16 shards through the host, ordered
-            # after the stream this runs on; RCCL takes the device tensors as they are
+        staged = t.is_cuda and self._host_staged
+        # the staging buffers of a bucket size live across steps (a step used to allocate four tensors per bucket on the
+        # communication stream); the padding of the last shard is zeroed once, at allocation
+        key = (n, "cpu" if staged else str(t.device))
+        bufs = self._wire_buf.get(key)
+        if bufs is None:
+            dev = "cpu" if staged else t.device
+            bufs = (torch.zeros(w * shard, dtype=torch.bfloat16, device=dev), torch.empty(w * shard, dtype=torch.bfloat16, device=dev),
+                    torch.empty(shard, dtype=torch.bfloat16, device=dev), torch.empty(w * shard, dtype=torch.bfloat16, device=dev))
+            self._wire_buf[key] = bufs
+        send, recv, mean, out = bufs
+        if staged:
+            # stage the bf16 shards through the host, ordered after the stream this runs on (RCCL takes the device
+            # tensors as they are)
             torch.cuda.current_stream(t.device).synchronize()
-            send = send.cpu()
-        recv = torch.empty_like(send)
+            send[:n].copy_(t.to(torch.bfloat16))
+        else:
+            send[:n].copy_(t)
         dist.all_to_all_single(recv, send, group=self.group)
-        mean = (recv.view(w, shard).float().sum(0) * (1.0 / w)).to(torch.bfloat16)
-        out = torch.empty(w * shard, dtype=torch.bfloat16, device=send.device)
+        mean.copy_(recv.view(w, shard).float().sum(0) * (1.0 / w))
         dist.all_gather_into_tensor(out, mean, group=self.group)
         t.copy_(out[:n])
         return None

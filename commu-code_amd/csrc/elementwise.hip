@@ -723,9 +723,10 @@ __global__ void sumsq_final_kernel(const float* __restrict__ part, int n, float*
 // lane and instruction the four pieces of a 16-byte unit left in four store instructions and the kernel wrote 1.3x its bytes).
 __device__ __forceinline__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                             float* __restrict__ v, bf16* __restrict__ pb, size_t n, float coef, float step,
-                                            float isb2, float b1, float b2, float eps) {
+                                            float isb2, float b1, float b2, float eps, bool vec) {
+    // (vec = false: a caller's slice that does not start on a 16-byte boundary -- same arithmetic, one element at a time)
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
-        if (i + 3 < n) {
+        if (vec && i + 3 < n) {
             const f32x4 g4 = *(const f32x4*)(g + i), m4 = *(const f32x4*)(m + i), v4 = *(const f32x4*)(v + i), p4 = *(const f32x4*)(p + i);
             f32x4 mo, vo, po;
             bf16x4 pbo;
@@ -744,7 +745,7 @@ __device__ __forceinline__ void adam_update(float* __restrict__ p, const float* 
             *(f32x4*)(p + i) = po;
             if (pb) *(bf16x4*)(pb + i) = pbo;
         } else {
-            for (size_t j = i; j < n; ++j) {
+            for (size_t j = i; j < n && j < i + 4; ++j) {
                 const float gr = g[j] * coef;
                 const float mm = b1 * m[j] + (1.f - b1) * gr;
                 const float vv = b2 * v[j] + (1.f - b2) * gr * gr;
@@ -762,10 +763,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16* __restrict__ pb, size_t n, float lr, float b1,
                                                    float b2, float eps, float bc1, float bc2,
-                                                   const float* __restrict__ gnorm, float clip) {
+                                                   const float* __restrict__ gnorm, float clip, bool vec) {
     float coef = 1.f;
     if (gnorm != nullptr && clip > 0.f) coef = fminf(1.f, clip / (gnorm[0] + 1e-6f));
-    adam_update(p, g, m, v, pb, n, coef, lr / bc1, 1.f / sqrtf(bc2), b1, b2, eps);
+    adam_update(p, g, m, v, pb, n, coef, lr / bc1, 1.f / sqrtf(bc2), b1, b2, eps, vec);
 }
 
 // the same step with lr and the two bias corrections read from DEVICE memory (scal = {lr, 1 - b1^t, 1 - b2^t}): what a
@@ -774,11 +775,11 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        bf16* __restrict__ pb, size_t n, const float* __restrict__ scal,
                                                        float b1, float b2, float eps,
-                                                       const float* __restrict__ gnorm, float clip) {
+                                                       const float* __restrict__ gnorm, float clip, bool vec) {
     float coef = 1.f;
     if (gnorm != nullptr && clip > 0.f) coef = fminf(1.f, clip / (gnorm[0] + 1e-6f));
     const float lr = scal[0], bc1 = scal[1], bc2 = scal[2];
-    adam_update(p, g, m, v, pb, n, coef, lr / bc1, 1.f / sqrtf(bc2), b1, b2, eps);
+    adam_update(p, g, m, v, pb, n, coef, lr / bc1, 1.f / sqrtf(bc2), b1, b2, eps, vec);
 }
 
 __global__ void scale_clip_kernel(float* __restrict__ g, size_t n, const float* __restrict__ gnorm, float clip) {
@@ -1287,7 +1288,8 @@ extern "C" int commu_grad_norm(const float* g, size_t n, float* part, int npart,
     return 0;
 }
 
-// (the kernels move 16 bytes per lane: fp32 vectors 16-byte aligned, the bf16 shadow 8-byte aligned)
+// (the vector body moves 16 bytes per lane: fp32 vectors 16-byte aligned, the bf16 shadow 8-byte aligned; any other slice
+//  of the flat buffers -- e.g. one parameter at an odd offset -- takes the element-wise body of the same kernel)
 static bool adam_misaligned(const void* p, const void* g, const void* m, const void* v, const void* pb) {
     return ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) != 0) || (((size_t)pb & 7) != 0);
 }
@@ -1296,10 +1298,10 @@ extern "C" int commu_adam_step(float* p, const float* g, float* m, float* v, voi
                                float lr, float beta1, float beta2, float eps, int step,
                                const float* gnorm, float clip, hipStream_t stream) {
     if (n == 0) return 0;
-    if (adam_misaligned(p, g, m, v, p_bf16)) return -22;
+    const bool vec = !adam_misaligned(p, g, m, v, p_bf16);
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     COMMU_LAUNCH(adam_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
-                       (bf16*)p_bf16, n, lr, beta1, beta2, eps, bc1, bc2, gnorm, clip);
+                       (bf16*)p_bf16, n, lr, beta1, beta2, eps, bc1, bc2, gnorm, clip, vec);
     COMMU_LAUNCH_CHECK();
     return 0;
 }
@@ -1308,9 +1310,9 @@ extern "C" int commu_adam_step_dev(float* p, const float* g, float* m, float* v,
                                    const float* scal, float beta1, float beta2, float eps, const float* gnorm,
                                    float clip, hipStream_t stream) {
     if (n == 0) return 0;
-    if (scal == nullptr || adam_misaligned(p, g, m, v, p_bf16)) return -22;
+    if (scal == nullptr) return -22;
     COMMU_LAUNCH(adam_dev_kernel, dim3(cap_blocks((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v,
-                 (bf16*)p_bf16, n, scal, beta1, beta2, eps, gnorm, clip);
+                 (bf16*)p_bf16, n, scal, beta1, beta2, eps, gnorm, clip, !adam_misaligned(p, g, m, v, p_bf16));
     COMMU_LAUNCH_CHECK();
     return 0;
 }

@@ -27,7 +27,8 @@ def parse_args():
     model_arg_parser.add_argument("--checkpoint_dir", type=str)
     # not in the reference (which is fp32 throughout, train.py:48): run generation in the reference's own arithmetic --
     # fp32 weights, activations, K/V cache and products -- instead of the bf16 throughput path.  The mode in which greedy
-    # decoding (--temperature 0) reproduces the reference's tokens without a margin condition.
+    # decoding (--temperature 0) reproduces the reference's tokens wherever the top-1 / top-2 logit gap exceeds fp32
+    # summation-order noise (~1e-6 of the logit range; the bf16 path needs a gap above its ~1e-2 logit error).
     model_arg_parser.add_argument("--parity", action="store_true")
     input_arg_parser.add_argument("--output_dir", type=str, required=True)
     input_arg_parser.add_argument("--bpm", type=int)

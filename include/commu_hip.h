@@ -244,7 +244,8 @@ int commu_loss_grad_groups(const int64_t* target, int n, int pad, const int* cnt
                            hipStream_t stream);
 
 /* ---- optimiser (clip_grad_norm_ + optim.Adam, train.py:159-165,442) on flat fp32 buffers
- * (commu_adam_step / _dev: p, g, m, v 16-byte aligned, p_bf16 8-byte aligned or null; -22 otherwise) */
+ * (commu_adam_step / _dev: the 16-byte vector body needs p, g, m, v 16-byte aligned and p_bf16 8-byte aligned or null; any other
+ *  slice runs the element-wise body of the same kernel -- same results) */
 int commu_grad_norm(const float* g, size_t n, float* part, int npart, float* out_norm, hipStream_t stream);
 int commu_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, float lr,
                     float beta1, float beta2, float eps, int step, const float* gnorm, float clip,
