@@ -592,6 +592,10 @@ EXTRA_ROWS = [
      dict(d_model=500, heads=10, d_inner=1000, tgt_len=128, mem_len=1024, batch_per_gpu=256, batch_chunk=4)),
     ("cfg5_L12_D1024_H16_DI2048_T2048_M2048_b8_bf16",
      dict(layers=12, d_model=1024, heads=16, d_inner=2048, tgt_len=2048, mem_len=2048, batch_per_gpu=8)),
+    # BASELINE.json configs[2] under the reference's STRONG-scaling semantics (train.py:396-397: batch_size // num_gpus columns per
+    # rank): the per-rank work of the 8-GPU job -- 8 sequences x 1024 tokens, the step replayed from hipGraphs -- measured on ONE
+    # GPU, with a PROJECTION (not a measurement: this pool has one GPU per box) of the 8-GPU step from it
+    ("strong_b8_L6_D512_T1024_b8_per_gpu", dict(batch_per_gpu=8, strong_projection=True)),
     # (configs[4] names "fp8 MFMA GEMMs": the MX-fp8 forward path exists and is tested -- `--fp8-forward` -- but it is a
     #  measured LOSS at every shape of this model (63.5 vs 60.6 ms at this row in round 3): it is not a bench row)
 ]
@@ -615,6 +619,9 @@ def extra_rows(args, dev):
                      "roofline": attention_roofline(a, prof, tps, elapsed, pscale)}
         if getattr(a, "cpu_row", False) and not args.no_cpu_baseline:
             rows[tag]["cpu_baseline"] = cpu_baseline(a)
+        if getattr(a, "strong_projection", False):
+            rows[tag]["launch"] = "hipGraph replay" if auto_graph(a) else "eager"
+            rows[tag]["projection_8gpu_NOT_MEASURED"] = strong_projection(a, 1e3 * elapsed / steps, tps)
         if a.mem_len > 0 and not getattr(a, "fp8_forward", False):
             # reset_mems ~ Bernoulli(T / avg_len), avg_len = 512 (capped at 1), so that the reset
             # path (memory tiles skipped per column, zero-filled distances in the backward) is inside a timed region;
@@ -634,6 +641,26 @@ def extra_rows(args, dev):
             rows[tag]["micro_batch_loop"] = {"passes_per_step": a.batch_chunk, "value": round(tps3 * steps / e3, 1),
                                              "ms_per_step": round(1e3 * e3 / steps, 3)}
     return rows
+
+
+def strong_projection(a, ms_rank, tokens_rank, n=8):
+    """PROJECTION (no multi-GPU hardware on this pool) of the n-GPU strong-scaling step of configs[2] from the measured
+    per-rank step: the gradient exchange is one mean all-reduce of the flat fp32 gradient (14.55 M parameters = 58.2 MB; 29.1 MB
+    on the bf16 wire), reduce-scatter + all-gather over the 7 xGMI links of a GPU (7 x 153 GB/s, MI355X_MICROARCH.md): each
+    phase moves (n-1)/n of the payload per GPU.  `overlapped`: the exchange hides behind the backward pass except its last bucket
+    (GradReducer: 16-MB buckets -> a quarter of the payload exposed); `serial`: nothing hidden; link efficiency 0.7 assumed."""
+    params = 14.55e6
+    link_gbs, links, eff = 153.0, 7, 0.7
+    out = {"assumptions": f"{links} xGMI links x {link_gbs} GB/s per GPU at {eff} efficiency; ring-free full-mesh reduce-scatter + "
+                          "all-gather; per-rank step as measured on one GPU (hipGraph replay); no straggler / launch skew term"}
+    for wire, bytes_per in (("fp32", 4), ("bf16", 2)):
+        payload = params * bytes_per
+        t_ms = 1e3 * 2.0 * (n - 1) / n * payload / (links * link_gbs * 1e9 * eff)
+        for mode, exposed in (("overlapped", 0.25), ("serial", 1.0)):
+            step = ms_rank + exposed * t_ms
+            out[f"{wire}_{mode}"] = {"exchange_ms": round(t_ms, 3), "step_ms": round(step, 3),
+                                     "tokens_per_s_total": round(n * tokens_rank / (step * 1e-3), 1)}
+    return out
 
 
 def launch_ranks(n, argv, popen=None, device_count=None):
