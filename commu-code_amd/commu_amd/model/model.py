@@ -624,12 +624,14 @@ class MemTransformerLM(nn.Module):
             lin = (lambda x, k, **e: ops.linear_mxfp8(x, f8[k], **e)) if fp8 else (lambda x, k, **e: ops.gemm_nt(x, w[k], **e))
             z1 = lin(vec, "o", resid=h, drop_p=p, drop_seed=ss(s0 + 1))                         # K7
             a, mu1, rs1 = ops.layernorm_fwd(z1, lay[i].dec_attn.layer_norm.weight, lay[i].dec_attn.layer_norm.bias)
-            # opt-in (model.relu_sign_bits = True): ReLU backward from ONE BIT per element, written by this GEMM's epilogue,
-            # instead of the bf16 activations.  Alone the backward GEMM drops from 123 to 84 us and this one costs 6 us more;
-            # inside the step (side streams running) the pair measured 0.07 ms SLOWER per step in 9 of 9 interleaved runs,
-            # so the bf16 mask stays the default
+            # ReLU backward from ONE BIT per element, written by this GEMM's epilogue, instead of the bf16 activations
+            # (model.relu_sign_bits, default on since round 6; bit-identical gradients, tests/test_model_gpu.py).  Alone the
+            # backward GEMM drops from 123 to 84 us and this one costs 6 us more, 0.75 GB less HBM traffic per step; inside the
+            # step the pair is worth 0.05 ms (15.73 -> 15.69 ms, 3 of 3 interleaved runs; in round 5, before the side-stream
+            # launches were re-balanced, it measured 0.07 ms slower and stayed off).  Shapes the bit path does not take fall
+            # back to the bf16 mask.
             hbits = None
-            if need_grad and not fp8 and getattr(self, "relu_sign_bits", False):
+            if need_grad and not fp8 and not gelu and getattr(self, "relu_sign_bits", True):
                 nw = ops.signbits_words(TB, DI, D, a.stride(0), w["w1"].stride(0), DI)
                 if nw > 0 and ops.signbits_words(TB, DI, D, D, D, DI) > 0:
                     hbits = torch.empty(nw, device=dev, dtype=torch.int32)

@@ -1601,7 +1601,8 @@ extern "C" long long commu_attn_p_scratch_elems(int T, int M, int B, int H) {
     return (long long)B * H * (2 * ((T + 31) / 32)) * ((T + M + 63) / 64) * 1024;          // (covers both block orders)
 }
 
-constexpr bool KV3_DEFAULT = false;          // the automatic choice (generation 0)
+constexpr bool KV3_DEFAULT = true;           // the automatic choice (generation 0): relattn_kv3.hip since round 6 (-0.10 ms per step, 3 of 3
+                                             // interleaved runs; equal in round 5, before the side-stream launches were re-balanced)
 constexpr bool Q3_DEFAULT = false;           // generation 0 takes the 32x32-layout pair (relattn_q3.hip + relattn_kv3.hip, p_layout 2)
 static int g_kv_gen = 0;
 extern "C" int commu_attn_bwd_kv_generation(int gen) {

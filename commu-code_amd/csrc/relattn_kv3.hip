@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         if (it_hi < it_lo) it_hi = it_lo - 1;
 
         // P blocks of this wave: sub-tile (qs, ks32) at ((qs KS32 + ks32) 2 KB); the lane's 32 bytes at key ii, half
-        const bf16* pwave = a.pbuf + bh * (size_t)(2 * ((T + 31) >> 5)) * JT * 1024 + (size_t)(jw >> 5) * 1024 + ii * 32 + half * 16;
+        // (a wave whose 32 keys lie beyond K -- the last 128-key tile of K % 128 <= 64 -- reads the last block column instead: unused,
+        //  but a plain load past the end of the scratch faults)
+        const bf16* pwave = a.pbuf + bh * (size_t)(2 * ((T + 31) >> 5)) * JT * 1024 + (size_t)min(jw >> 5, KS32 - 1) * 1024 + ii * 32 + half * 16;
         const int QS = (T + 31) >> 5;
         bf16x8 pn[2][2];
         auto pfetch = [&](int it) {          // (clamped: a block past the end is somebody else's and is not used)

@@ -651,6 +651,9 @@ ATTN_CASES = [
     # steps: the last slices are empty; 16 pairs with memory)
     (128, 0, 64, 10, 64, False, 0, None),
     (64, 64, 128, 16, 64, False, 64, None),
+    # memory as long as the segment with a reset column at a small batch (the shape of tests/test_configs_gpu.py's graph-step
+    # case: the 32x32 key-stationary kernel as the default aborted there in round 6)
+    (64, 64, 8, 4, 64, False, 64, 1),
 ]
 
 

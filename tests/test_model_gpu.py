@@ -478,8 +478,8 @@ def test_generate_cli_from_a_reference_checkpoint(golden_dir, tmp_path):
 
 @pytest.mark.gpu
 def test_relu_sign_bits_option_gives_identical_gradients(monkeypatch):
-    """model.relu_sign_bits (opt-in): the FF ReLU backward reads one bit per element written by the forward GEMM instead of
-    the bf16 activations -- same loss, same gradients (dropout on, same seeds)."""
+    """model.relu_sign_bits (the default; False: the bf16 activations as the mask): the FF ReLU backward reads one bit per element
+    written by the forward GEMM instead of the bf16 activations -- same loss, same gradients (dropout on, same seeds)."""
     from commu_amd.model.config_helper import get_cfg
     from commu_amd.model.dataset import BaseVocab, synthetic_batch
     from commu_amd.train import build_model
