@@ -19,6 +19,16 @@ SWITCH = {
     "tn8_160": lambda on: os.environ.__setitem__("COMMU_TN8_WGS", "160") if on else os.environ.pop("COMMU_TN8_WGS", None),
     "tn8_192": lambda on: os.environ.__setitem__("COMMU_TN8_WGS", "192") if on else os.environ.pop("COMMU_TN8_WGS", None),
 }
+
+
+def env_switch(spec):          # "env:NAME=VALUE": an environment variable the library reads at every call
+    name, val = spec[4:].split("=", 1)
+    return lambda on: os.environ.__setitem__(name, val) if on else os.environ.pop(name, None)
+
+
+for a in sys.argv[1:]:
+    if a.startswith("env:"):
+        SWITCH[a] = env_switch(a)
 dev = torch.device("cuda", 0)
 cfg = get_cfg()
 model = build_model(cfg, BaseVocab(), dev, seed=1)
