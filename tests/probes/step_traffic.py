@@ -84,7 +84,7 @@ from commu_amd import source_stamp          # the same stamp bench.py computes: 
 out = {"shape": [6, 512, 8, 1024, 0, 64], "source_sha256": source_stamp.kernel_source_hash(), "switches": source_stamp.traffic_switches(), "steps_in_run": steps,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python3 bench.py --steps 4 "
                  "--warmup 2 --no-cpu-baseline --no-decode --no-extra`; bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, summed over every "
-                 "dispatch of the run and divided by its optimiser steps (the first step's one-off initialisation included)",
+                 "dispatch of the run and divided by its optimiser steps (warm-up, timed and event-sampled steps; the first step's one-off initialisation included)",
        "calibration": cal, "step_hbm_bytes": total,
        "step_read_bytes": sum(r["read_bytes_per_step"] for r in rows.values()),
        "step_write_bytes": sum(r["write_bytes_per_step"] for r in rows.values()),
