@@ -1723,8 +1723,10 @@ static int launch_relattn_bwd(const commu_attn_desc* d, const commu_attn_bwd_des
             COMMU_LAUNCH_CHECK();
             return 0;
         }
+        // generation 0 (the default): the 16x16 query-stationary kernel with its whole-line P stores (p_layout 0) and
+        // relattn_kv3.hip reading that order; 3: the same pair with the 32x32 block order (p_layout 1); 2: the 16x16 pair
         const bool kv3 = KV3_DEFAULT ? g_kv_gen != 2 : g_kv_gen == 3;
-        a.p_layout = kv3 ? 1 : 0;
+        a.p_layout = (kv3 && g_kv_gen == 3) ? 1 : 0;
         const bool fromp = a.pf != nullptr;          // probabilities saved by the forward pass: no score recomputation
         if (drop) {
             if ((which & 1) && fromp) COMMU_LAUNCH((relattn_bwd_q_kernel<64, 4, true, true>), gq, dim3(256), 0, stream, a);

@@ -40,8 +40,12 @@ constexpr int TILEB = 8192;          // one [64 q][64 f] bf16 tile
 // two LDS-DMA instructions (slot 4 query + 2 half + k, so that the reads below are conflict-free) and fetches the 16 queries of
 // its key with four ds_read_b64_tr_b16; the transpose hands lane l the key (l & 31) ^ 3 of the block (the quads are stored
 // reversed), so the V^T fragments and the dk / dv rows use that key order too.
-template <bool DROP, bool P2>
+// PL = AttnArgs.p_layout.  0: the block order of the 16x16 pair (relattn_bwd_q_kernel's whole-line stores; four 8-byte loads per
+// lane and 32x32 block) -- the default pairing since round 6: with p_layout 1 the query-stationary kernel's 8-byte P pieces cost it
+// +0.23 GB of written bytes per launch (WRITE_SIZE: 1.47 against 1.24 GB), which ate the gain of this kernel inside the step.
+template <bool DROP, int PL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void relattn_bwd_kv3_kernel(const AttnArgs a) {
+    constexpr bool P2 = PL == 2;
     __shared__ __attribute__((aligned(1024))) char smem[4 * TILEB + 2 * 256 + (P2 ? 4 * 4096 : 0)];          // dO x2, (q+u) x2, delta x2, P blocks
     constexpr int OFF_O = 0, OFF_Q = 2 * TILEB, OFF_D = 4 * TILEB, OFF_P = 4 * TILEB + 512;
     const LDS_AS char* lds = (const LDS_AS char*)smem;
@@ -140,7 +144,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const bf16* pwave = a.pbuf + bh * (size_t)(2 * ((T + 31) >> 5)) * JT * 1024 + (size_t)min(jw >> 5, KS32 - 1) * 1024 + ii * 32 + half * 16;
         const int QS = (T + 31) >> 5;
         bf16x8 pn[2][2];
+        // PL 0: blocks of [64 keys][16 rows] (2 KB, [B*H][ceil(T/16)][JT]); key k's 16 rows are 32 contiguous bytes, the four
+        // 4-row slots s at physical slot s ^ ((k >> 2) & 3) (relattn.hip pt_off).  The lane's registers 8 blk + 4 x + e are rows
+        // 16 blk + 8 x + 4 half + e of the 32-query block: slot 2 x + half of 16-row block blk
+        const int QB16 = (T + 15) >> 4;
+        const int k64 = (jw & 63) + ii, ksw = (k64 >> 2) & 3;
+        const bf16* pwave0 = a.pbuf + (bh * (size_t)QB16 * JT + (size_t)min(jw >> 6, JT - 1)) * 1024 + k64 * 16;
         auto pfetch = [&](int it) {          // (clamped: a block past the end is somebody else's and is not used)
+            if (PL == 0) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const bf16* p = pwave0 + (size_t)min(2 * (2 * it + qb) + blk, QB16 - 1) * JT * 1024;
+                        const bf16x4 lo = *(const bf16x4*)(p + ((half ^ ksw) << 2)), hi = *(const bf16x4*)(p + (((2 + half) ^ ksw) << 2));
+                        pn[qb][blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                return;
+            }
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const bf16* p = pwave + (size_t)min(2 * it + qb, QS - 1) * KS32 * 1024;
@@ -277,11 +298,16 @@ int launch_relattn_bwd_kv3(const AttnArgs& a, hipStream_t stream) {
     const int K = a.T + a.M, NT = (K + 127) / 128;
     const dim3 grid(((NT + 1) / 2) * a.H * a.B);
     if (a.p_layout == 2) {
-        if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, true>), grid, dim3(256), 0, stream, a);
-        else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, true>), grid, dim3(256), 0, stream, a);
+        if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, 2>), grid, dim3(256), 0, stream, a);
+        else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, 2>), grid, dim3(256), 0, stream, a);
         return 0;
     }
-    if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, false>), grid, dim3(256), 0, stream, a);
-    else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, false>), grid, dim3(256), 0, stream, a);
+    if (a.p_layout == 0) {
+        if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, 0>), grid, dim3(256), 0, stream, a);
+        else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, 0>), grid, dim3(256), 0, stream, a);
+        return 0;
+    }
+    if (a.drop_thr != 0u) COMMU_LAUNCH((relattn_bwd_kv3_kernel<true, 1>), grid, dim3(256), 0, stream, a);
+    else COMMU_LAUNCH((relattn_bwd_kv3_kernel<false, 1>), grid, dim3(256), 0, stream, a);
     return 0;
 }

@@ -715,8 +715,8 @@ def test_relattn_bwd_delta_inside_the_query_kernel():
         assert relerr(b_, a_) < 2e-3
 
 
-@pytest.mark.parametrize("store_p", [False, True, 3, 4, "fwd_p", "fwd_p_kv3"],
-                         ids=["recompute", "stored_p", "stored_p_kv3", "stored_p_q3", "forward_p", "forward_p_kv3"])
+@pytest.mark.parametrize("store_p", [False, True, 3, 4, 5, "fwd_p", "fwd_p_kv3"],
+                         ids=["recompute", "stored_p", "stored_p_kv3", "stored_p_q3", "stored_p_default", "forward_p", "forward_p_kv3"])
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_relattn_bwd(case, store_p):
     """store_p: the query-stationary kernel writes the probabilities it recomputes into a scratch buffer (poisoned with
@@ -764,7 +764,8 @@ def test_relattn_bwd(case, store_p):
     #  of the scratch that goes with it; stored_p: the 16x16-layout kernel)
     # (stored_p_q3: both backward kernels on the 32x32 MFMA -- relattn_q3.hip stores P in its own accumulator order,
     #  relattn_kv3.hip transposes the blocks through LDS)
-    prev_kv = o.attn_bwd_kv_generation(store_p if store_p in (3, 4) else 2)
+    # (stored_p_default: generation 0 = the 16x16 query-stationary kernel's whole-line block order read by relattn_kv3.hip)
+    prev_kv = o.attn_bwd_kv_generation(store_p if store_p in (3, 4) else (0 if store_p == 5 else 2))
     try:
         o.relattn_bwd(q, k, v, rd.to(DEV), u.to(DEV), vb.to(DEV), rst, T, M, B, H, DH, sl, mem_len, out,
                       dout.to(DEV), lse, qs, dqkv[M * B:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], drd, du, dvb)
