@@ -10,7 +10,8 @@ from collections import defaultdict
 
 KERNELS = {"relattn_fwd2_kernel": "commu_relattn_fwd", "relattn_fwd3_kernel": "commu_relattn_fwd", "relattn_fwd_kernel": "commu_relattn_fwd",
            "relattn_bwd_q_kernel": "commu_relattn_bwd_q", "relattn_bwd_kv2_kernel": "commu_relattn_bwd_kv",
-           "relattn_bwd_kv_kernel": "commu_relattn_bwd_kv"}
+           "relattn_bwd_kv_kernel": "commu_relattn_bwd_kv", "relattn_bwd_kv3_kernel": "commu_relattn_bwd_kv",
+           "relattn_bwd_q3_kernel": "commu_relattn_bwd_q"}
 
 
 def per_launch(db, counter):
