@@ -81,6 +81,7 @@ PROTOTYPES = {
     "commu_layernorm_fwd": [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_layernorm_bwd_nblocks": [c_i],
     "commu_layernorm_bwd": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, C.c_uint, c_f, c_p],
+    "commu_layernorm_bwd_add": [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, C.c_uint, c_f, c_p],
     "commu_colsum_slabs": [c_i, c_i, c_i],
     "commu_colsum_bf16": [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_f, c_p],
     "commu_colsum_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_f, c_p],

@@ -863,6 +863,7 @@ class MemTransformerLM(nn.Module):
                 side2.wait_event(side_mark[0])
                 fn()
 
+        dy_add = None
         for i in range(L - 1, -1, -1):
             pre = f"layers.{i}."
             lay = self.layers[i]
@@ -872,7 +873,8 @@ class MemTransformerLM(nn.Module):
                 side_mark[0].record(side)
             dz2m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz2, part = ops.layernorm_bwd(dy, sv.z2[i], sv.mu2[i], sv.rs2[i], lay.pos_ff.layer_norm.weight,
-                                          dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3))
+                                          dz_masked=dz2m, drop_p=p, drop_seed=ss(s0 + 3), add=dy_add)
+            dy_add = None
             if dz2m is None:
                 dz2m = dz2
             keep.append(part)
@@ -890,10 +892,13 @@ class MemTransformerLM(nn.Module):
             # (the bias gradient = column sums of dhid comes out of the weight-gradient launch: no pass of its own)
             wgrad(dhid, sv.a[i], gv(pre + "pos_ff.CoreNet.0.weight", (DIt, Dt)), crop=spec("w1"),
                   colsum=(gv(pre + "pos_ff.CoreNet.0.bias", (DIt,)), DIt))
-            da = ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
+            # (model.resid_in_ln_bwd, A/B: the residual branch's gradient as a second addend of the LayerNorm backward that
+            #  consumes the sum, instead of an auxiliary operand of the dX GEMM -- which then takes the pipelined epilogue)
+            rln = bool(getattr(self, "resid_in_ln_bwd", False))
+            da = ops.gemm_nt(dhid, sh[f"w1_t{i}"]) if rln else ops.gemm_nt(dhid, sh[f"w1_t{i}"], resid=dz2)
             dz1m = torch.empty(TB, D, device=dev, dtype=BF16) if p > 0 else None
             dz1, part = ops.layernorm_bwd(da, sv.z1[i], sv.mu1[i], sv.rs1[i], lay.dec_attn.layer_norm.weight,
-                                          dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1))
+                                          dz_masked=dz1m, drop_p=p, drop_seed=ss(s0 + 1), add=dz2 if rln else None)
             if dz1m is None:
                 dz1m = dz1
             keep.append(part)
@@ -945,7 +950,11 @@ class MemTransformerLM(nn.Module):
             if M > 0:
                 wgrad(dqkv[:M * B, HD:], sv.cat[i], gW[HDt:], crop=spec("kv"))
             flush_wgrads(wide=last and not getattr(self, "narrow_last_wgrad", False))          # (attribute: A/B runs only)
-            dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
+            if rln and not last:          # (the layer below's LayerNorm backward adds dz1; the embedding scatter needs the sum)
+                dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"])
+                dy_add = dz1
+            else:
+                dy = ops.gemm_nt(dqkv[M * B:], sh[f"qkv_t{i}"], resid=dz1)
             hook = getattr(self, "grad_ready_hook", None)
             if hook is not None and direct:
                 # every gradient of layer i is final once what has been enqueued so far on BOTH streams has run: its

@@ -438,14 +438,20 @@ def layernorm_fwd(z, gamma, beta, y=None, mean=None, rstd=None, eps=1e-5, y_drop
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, drop_p=0.0, drop_seed=0):
+def layernorm_bwd(dy, z, mean, rstd, gamma, dz=None, part=None, dz_masked=None, drop_p=0.0, drop_seed=0, add=None):
     """Returns (dz, part) with part [nblk, 3, D]: partial column sums of dy*xhat, dy, dz (or of
-    dz_masked = dz * keep/(1-p) when that second output is requested).  D = gamma.numel()."""
+    dz_masked = dz * keep/(1-p) when that second output is requested).  D = gamma.numel().
+    add (optional, bf16 like dy): the incoming gradient is dy + add (a residual branch's gradient)."""
     rows, D = z.shape[0], gamma.numel()
     nblk = call("commu_layernorm_bwd_nblocks", rows)
     dz = torch.empty_like(z) if dz is None else dz
     if part is None:
         part = torch.empty(nblk, 3, D, device=z.device, dtype=F32)
+    if add is not None:
+        call("commu_layernorm_bwd_add", _p(dy), dy.stride(0), _p(add), add.stride(0), _p(z), z.stride(0), _p(mean), _p(rstd),
+             _p(gamma), _p(dz), dz.stride(0), _p(part), rows, D, _p(dz_masked), 0 if dz_masked is None else dz_masked.stride(0),
+             int(drop_seed), float(drop_p), _s())
+        return dz, part[:nblk]
     call("commu_layernorm_bwd", _p(dy), dy.stride(0), _p(z), z.stride(0), _p(mean), _p(rstd), _p(gamma), _p(dz),
          dz.stride(0), _p(part), rows, D, _p(dz_masked), 0 if dz_masked is None else dz_masked.stride(0),
          int(drop_seed), float(drop_p), _s())

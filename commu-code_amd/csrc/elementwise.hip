@@ -349,9 +349,11 @@ constexpr int LNB_WROWS = LNB_ROWS / 4;
 
 // Bandwidth kernel (2 reads + 2 writes of a [rows, D] bf16 tensor): a wave walks its rows TWO at a time -- two independent
 // reduction chains -- with the next pair's operands and row statistics already in flight (4 rows x 2 x 16 bytes per lane).
-template <int NC>          // NC 8-element chunks per lane: D <= 512 * NC
+// ADD: the incoming gradient is dy + dy2 (the residual branch's gradient as a second addend HERE instead of an auxiliary
+// operand in the epilogue of the GEMM that produced dy: that GEMM then takes the pipelined epilogue)
+template <int NC, bool ADD = false>          // NC 8-element chunks per lane: D <= 512 * NC
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
-    const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ z, int ldz,
+    const bf16* __restrict__ dy, int lddy, const bf16* __restrict__ dy2, int lddy2, const bf16* __restrict__ z, int ldz,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
     bf16* __restrict__ dz, int lddz, float* __restrict__ part, int rows, int D, bf16* __restrict__ dzm,
     int lddzm, unsigned drop_seed, unsigned drop_thr, float drop_scale) {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const DropKey key = drop_key(salted(drop_seed));
     const float invD = 1.f / (float)D;
-    bf16x8 vz[2][NC], vd[2][NC], nz[2][NC], nd[2][NC];
+    bf16x8 vz[2][NC], vd[2][NC], nz[2][NC], nd[2][NC], ve[2][ADD ? NC : 1], ne[2][ADD ? NC : 1];
     float vmu[2], vrs[2], nmu[2], nrs[2];
     auto fetch = [&](int row) {          // rows row, row+1 (clamped: a pair past the end re-reads the last row, unused)
 #pragma unroll
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                 const int col = lane * 8 + 512 * c;
                 nz[u][c] = act[c] ? ld_bf16x8(z + (size_t)r * ldz + col) : zero8;
                 nd[u][c] = act[c] ? ld_bf16x8(dy + (size_t)r * lddy + col) : zero8;
+                if (ADD) ne[u][c] = act[c] ? ld_bf16x8(dy2 + (size_t)r * lddy2 + col) : zero8;
             }
         }
     };
@@ -400,7 +403,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
             vmu[u] = nmu[u];
             vrs[u] = nrs[u];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { vz[u][c] = nz[u][c]; vd[u][c] = nd[u][c]; }
+            for (int c = 0; c < NC; ++c) {
+                vz[u][c] = nz[u][c];
+                vd[u][c] = nd[u][c];
+                if (ADD) ve[u][c] = ne[u][c];
+            }
         }
         if (rr + 2 < nr) fetch(r0 + rr + 2);          // the next pair's loads fly under this pair's reductions
         float xh[2][NC][8], gy[2][NC][8], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const bool ok = live && act[c] && (e < 4 || hi[c]);
-                    const float d = ok ? bf2f(vd[u][c][e]) : 0.f;
+                    const float d = ok ? (ADD ? bf2f(vd[u][c][e]) + bf2f(ve[u][c][e]) : bf2f(vd[u][c][e])) : 0.f;
                     xh[u][c][e] = ok ? (bf2f(vz[u][c][e]) - vmu[u]) * vrs[u] : 0.f;
                     gy[u][c][e] = d * gm[c][e];
                     s1[u] += gy[u][c][e];
@@ -1069,25 +1076,45 @@ extern "C" int commu_layernorm_fwd(const void* z, int ldz, const float* gamma, c
 
 extern "C" int commu_layernorm_bwd_nblocks(int rows) { return (rows + LNB_ROWS - 1) / LNB_ROWS; }
 
+static int layernorm_bwd_launch(const void* dy, int lddy, const void* dy2, int lddy2, const void* z, int ldz, const float* mean,
+                                const float* rstd, const float* gamma, void* dz, int lddz, float* part, int rows, int D,
+                                void* dz_masked, int lddzm, unsigned drop_seed, float drop_p, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const int D8 = (D + 7) & ~7;
+    if (D > 1024 || (D % 4) || (lddy % 8) || (ldz % 8) || (lddz % 8) || lddy < D8 || ldz < D8 || lddz < D8 ||
+        (dz_masked != nullptr && lddzm != lddz) || (dy2 != nullptr && ((lddy2 % 8) || lddy2 < D8)))
+        return -22;
+#define LNB(NCV, ADDV)                                                                                                          \
+    COMMU_LAUNCH((layernorm_bwd_kernel<NCV, ADDV>), dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,               \
+                 (const bf16*)dy, lddy, (const bf16*)dy2, lddy2, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part,  \
+                 rows, D, (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)))
+    if (D <= 512) {
+        if (dy2 != nullptr) LNB(1, true);
+        else LNB(1, false);
+    } else {
+        if (dy2 != nullptr) LNB(2, true);
+        else LNB(2, false);
+    }
+#undef LNB
+    COMMU_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const float* mean,
                                    const float* rstd, const float* gamma, void* dz, int lddz,
                                    float* part, int rows, int D, void* dz_masked, int lddzm,
                                    unsigned drop_seed, float drop_p, hipStream_t stream) {
-    if (rows <= 0) return 0;
-    const int D8 = (D + 7) & ~7;
-    if (D > 1024 || (D % 4) || (lddy % 8) || (ldz % 8) || (lddz % 8) || lddy < D8 || ldz < D8 || lddz < D8 ||
-        (dz_masked != nullptr && lddzm != lddz))
-        return -22;
-    if (D <= 512)
-        COMMU_LAUNCH(layernorm_bwd_kernel<1>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
-                     (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,
-                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
-    else
-        COMMU_LAUNCH(layernorm_bwd_kernel<2>, dim3(commu_layernorm_bwd_nblocks(rows)), dim3(256), 0, stream,
-                     (const bf16*)dy, lddy, (const bf16*)z, ldz, mean, rstd, gamma, (bf16*)dz, lddz, part, rows, D,
-                     (bf16*)dz_masked, lddzm, drop_seed, drop_threshold(drop_p), drop_keep_scale16(drop_threshold(drop_p)));
-    COMMU_LAUNCH_CHECK();
-    return 0;
+    return layernorm_bwd_launch(dy, lddy, nullptr, 0, z, ldz, mean, rstd, gamma, dz, lddz, part, rows, D, dz_masked, lddzm,
+                                drop_seed, drop_p, stream);
+}
+
+extern "C" int commu_layernorm_bwd_add(const void* dy, int lddy, const void* dy2, int lddy2, const void* z, int ldz,
+                                       const float* mean, const float* rstd, const float* gamma, void* dz, int lddz,
+                                       float* part, int rows, int D, void* dz_masked, int lddzm, unsigned drop_seed,
+                                       float drop_p, hipStream_t stream) {
+    if (dy2 == nullptr) return -22;
+    return layernorm_bwd_launch(dy, lddy, dy2, lddy2, z, ldz, mean, rstd, gamma, dz, lddz, part, rows, D, dz_masked, lddzm,
+                                drop_seed, drop_p, stream);
 }
 
 /* rows of the fp32 workspace (`cols` rounded up to 8 floats each) the column sum of a rows x cols input needs;

@@ -188,6 +188,12 @@ int commu_layernorm_bwd(const void* dy, int lddy, const void* z, int ldz, const 
                         const float* rstd, const float* gamma, void* dz, int lddz, float* part, int rows,
                         int D, void* dz_masked, int lddzm, unsigned drop_seed, float drop_p,
                         hipStream_t stream);
+/* the same with the incoming gradient dy + dy2 (both bf16, summed in fp32): the gradient of a residual branch as a second
+ * addend of the LayerNorm backward instead of an auxiliary operand of the GEMM that produced dy (model.py:174-181,348-352) */
+int commu_layernorm_bwd_add(const void* dy, int lddy, const void* dy2, int lddy2, const void* z, int ldz,
+                            const float* mean, const float* rstd, const float* gamma, void* dz, int lddz, float* part,
+                            int rows, int D, void* dz_masked, int lddzm, unsigned drop_seed, float drop_p,
+                            hipStream_t stream);
 /* dgamma += sum_blocks part[:,0,:], dbeta += part[:,1,:], dbias += part[:,2,:] (each destination optional) */
 int commu_layernorm_bwd_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta, float* dbias,
                                hipStream_t stream);

@@ -504,6 +504,35 @@ def test_relu_sign_bits_option_gives_identical_gradients(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_residual_gradient_in_layernorm_backward_option():
+    """model.resid_in_ln_bwd (opt-in, commu_layernorm_bwd_add): the residual branch's gradient enters the LayerNorm backward as a
+    second addend instead of the dX GEMM's epilogue -- the same gradients up to the bf16 rounding of one intermediate (the sum
+    is no longer rounded before the LayerNorm backward reads it).  Two segments with XL memory, reset columns, dropout on."""
+    from commu_amd.model.config_helper import get_cfg
+    from commu_amd.model.dataset import BaseVocab, synthetic_batch
+    from commu_amd.train import build_model
+    dev = torch.device("cuda", 0)
+    cfg = get_cfg(num_layers=3, num_heads=4, units=256, inner_size=512, tgt_length=128, mem_length=64, batch_size=8,
+                  batch_chunk=1, dropout=0.1, attention_dropout=0.1)
+    segs = [synthetic_batch(128, 8, dev, seed=30 + i, reset_prob=0.3) for i in range(2)]
+    out = []
+    for flag in (False, True):
+        model = build_model(cfg, BaseVocab(), dev, seed=5)
+        model.train()
+        model.resid_in_ln_bwd = flag
+        model.fixed_drop_seed = 77
+        mems = None
+        model.zero_grad()
+        for d, t, r, _ in segs:
+            loss, mems = model(d, t, r, mems)
+            loss.float().mean().backward()
+        out.append([p.grad.detach().clone() for p in model.parameters()])
+    for ga, gb in zip(*out):
+        assert float((ga - gb).abs().max()) <= 2e-2 * float(ga.abs().max()) + 1e-12          # (measured: 8e-3)
+        assert float(torch.dot(ga.flatten(), gb.flatten()) / (ga.norm() * gb.norm() + 1e-30)) > 0.9995
+
+
+@pytest.mark.gpu
 def test_forward_saved_probabilities_option_gives_the_same_step(monkeypatch):
     """ops.FWD_SAVES_P (opt-in): the training forward of d_head 64 saves its probabilities and the query-stationary
     backward kernel reads them instead of recomputing scores.  Two segments with XL memory, reset columns and dropout on
