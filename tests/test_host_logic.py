@@ -351,3 +351,52 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
     seen.clear()
     assert bench.launch_ranks(2, ["--gpus", "2"], popen=FakeProc, device_count=1) != 0 and not seen      # too few GPUs: no launch
+
+
+def test_profile_stamp_covers_every_kernel_source_and_the_traffic_switches(tmp_path, monkeypatch):
+    """bench.py reports the HBM bytes of a committed PMC profile only when the profile's stamp matches the tree: the stamp
+    hashes EVERY csrc/*.hip / *.h file plus ops.py and model.py (round 5's stamp skipped elementwise.hip, gemm.hip, ...), and
+    the switches that change a step's traffic without changing a source file are part of the match."""
+    import argparse
+    import json
+    import shutil
+    import bench
+    from commu_amd import source_stamp
+    files = sorted(f for f in os.listdir(source_stamp.CSRC) if f.endswith((".hip", ".h")))
+    assert {"elementwise.hip", "gemm.hip", "gemm8.hip", "relattn.hip", "relattn_kv3.hip", "band.hip", "common.h"} <= set(files)
+    h0 = source_stamp.kernel_source_hash()
+    # a change in ANY kernel source changes the stamp (here: a scratch copy of the source tree with one file touched)
+    csrc2 = tmp_path / "csrc"
+    shutil.copytree(source_stamp.CSRC, csrc2)
+    monkeypatch.setattr(source_stamp, "CSRC", str(csrc2))
+    assert source_stamp.kernel_source_hash() == h0
+    with open(csrc2 / "elementwise.hip", "a") as f:
+        f.write("\n// touched\n")
+    assert source_stamp.kernel_source_hash() != h0
+    monkeypatch.undo()
+    # the committed round-6 profiles carry stamp + switches; a flipped switch refuses them
+    args = argparse.Namespace(layers=6, d_model=512, heads=8, tgt_len=1024, mem_len=0, batch_per_gpu=64, batch_chunk=1,
+                              merge_chunks=None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r06_step_traffic.json")) as f:
+        rec = json.load(f)
+    assert set(rec["switches"]) == {"FWD_SAVES_P", "DELTA_KERNEL", "STORE_ATTN_P"}
+    if rec["source_sha256"] == h0:          # (a later edit of a kernel source legitimately invalidates the profile)
+        assert bench.step_traffic(args)["bytes"] == rec["step_hbm_bytes"]
+        from commu_amd import ops
+        monkeypatch.setattr(ops, "DELTA_KERNEL", not ops.DELTA_KERNEL)
+        assert bench.step_traffic(args) is None and bench.pmc_traffic("commu_relattn_bwd_q", args) is None
+    else:
+        assert bench.step_traffic(args) is None
+
+
+def test_strong_scaling_projection_arithmetic():
+    """extra_rows.strong_b8...projection_8gpu_NOT_MEASURED: exchange = 2 (n-1)/n payload / (7 links x 153 GB/s x 0.7)."""
+    import argparse
+    import bench
+    p = bench.strong_projection(argparse.Namespace(), ms_rank=4.0, tokens_rank=8192, n=8)
+    want = 1e3 * 2 * 7 / 8 * 14.55e6 * 4 / (7 * 153e9 * 0.7)
+    assert abs(p["fp32_serial"]["exchange_ms"] - want) < 2e-3 and abs(p["bf16_serial"]["exchange_ms"] - want / 2) < 2e-3
+    assert p["fp32_overlapped"]["step_ms"] < p["fp32_serial"]["step_ms"] < 4.0 + want + 1e-3
+    assert abs(p["fp32_serial"]["tokens_per_s_total"] - 8 * 8192 / (p["fp32_serial"]["step_ms"] * 1e-3)) < 1.0
+    assert "NOT" not in p["assumptions"] and "no straggler" in p["assumptions"]
