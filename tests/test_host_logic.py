@@ -398,5 +398,6 @@ def test_strong_scaling_projection_arithmetic():
     want = 1e3 * 2 * 7 / 8 * 14.55e6 * 4 / (7 * 153e9 * 0.7)
     assert abs(p["fp32_serial"]["exchange_ms"] - want) < 2e-3 and abs(p["bf16_serial"]["exchange_ms"] - want / 2) < 2e-3
     assert p["fp32_overlapped"]["step_ms"] < p["fp32_serial"]["step_ms"] < 4.0 + want + 1e-3
-    assert abs(p["fp32_serial"]["tokens_per_s_total"] - 8 * 8192 / (p["fp32_serial"]["step_ms"] * 1e-3)) < 1.0
+    want_rate = 8 * 8192 / (p["fp32_serial"]["step_ms"] * 1e-3)          # (step_ms is rounded to a microsecond in the record)
+    assert abs(p["fp32_serial"]["tokens_per_s_total"] - want_rate) < 2e-4 * want_rate
     assert "NOT" not in p["assumptions"] and "no straggler" in p["assumptions"]
